@@ -1,0 +1,151 @@
+/*
+ * rt_amd.h — C ABI of the MI355X trace/shade path.
+ *
+ * This library replaces exactly one thing in matheusmortatti/Ray-Tracer: the
+ * body of render() (renderer.cpp:7-141) together with check_intersection()
+ * (renderer.cpp:145-193) and the math it calls (maths.cpp:5-168).  Everything
+ * the reference keeps on the host (scene file parsing, the sphere-grid
+ * generator, the viewer, the PPM dump) calls in through the functions below.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross the boundary
+ *   - every function returns RT_OK (0) or a negative rt_status;
+ *     rt_last_error() gives the text of the last failure on this thread
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP
+ *     device memory on the device the rt_scene was created on
+ *   - framebuffer layout is the reference's (renderer.cpp:47-53): row-major,
+ *     top row first, 4 bytes per pixel; bytes 0..2 are the accumulated colour
+ *     in scene-file channel order, byte 3 is 255
+ *   - hit-id buffer: one int32 per pixel; -1 = miss, [0,t_size) = triangle
+ *     index, t_size + [0,s_size) = sphere index, i.e. the position of the
+ *     primitive in the order check_intersection tests them
+ *     (renderer.cpp:156,168)
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_BAD_ARG = -1,      /* null pointer, negative size, w/h <= 0 ... */
+  RT_ERR_NO_DEVICE = -2,    /* no HIP device visible */
+  RT_ERR_HIP = -3,          /* a HIP runtime call failed */
+  RT_ERR_CAPACITY = -4,     /* secondary-ray queue could not be sized */
+  RT_ERR_UNSUPPORTED = -5
+} rt_status;
+
+/*
+ * Per-primitive material.  NOT in the reference: there a primitive carries
+ * only an 8-bit colour (main.cpp:287-289, 297-299) and every surface is
+ * Phong with KS 0.3 / KD 0.7 / exponent 20 (renderer.cpp:3-5).  A scene whose
+ * material pointers are NULL, or whose materials are all zero, renders exactly
+ * as the reference does at any max_depth.
+ */
+typedef struct rt_material {
+  float reflectivity; /* weight of the mirror bounce, 0..1 */
+  float transparency; /* weight of the refracted bounce, 0..1 */
+  float ior;          /* index of refraction (> 0) for the refracted bounce */
+  float reserved;
+} rt_material;
+
+/*
+ * The eleven scene arguments of render() (renderer.hpp:16-18), as one struct.
+ * Layouts are the reference's flat arrays (built at main.cpp:270-305 and
+ * main.cpp:377-392).  The library only reads these.
+ */
+typedef struct scene_desc {
+  const float *tris;           /* 9*t_size : p1.xyz p2.xyz p3.xyz per triangle */
+  const uint8_t *color_tri;    /* 3*t_size */
+  int32_t t_size;
+  const float *spheres;        /* 3*s_size : centre.xyz */
+  const float *radius;         /* s_size */
+  const uint8_t *color_sphere; /* 3*s_size */
+  int32_t s_size;
+  const float *lights;         /* 3*l_size : position.xyz */
+  int32_t l_size;
+  const rt_material *mat_tri;    /* t_size entries or NULL (extension) */
+  const rt_material *mat_sphere; /* s_size entries or NULL (extension) */
+} scene_desc;
+
+/*
+ * The reference has no camera object: eye (0,0,1) (renderer.cpp:39), image
+ * plane z=-1 (renderer.cpp:38), fov an int in degrees (main.cpp:88).
+ * rt_camera_default() fills exactly those values.
+ */
+typedef struct camera {
+  int32_t fov_deg;
+  float origin[3];
+  float plane_z;
+} camera;
+
+void rt_camera_default(camera *cam);
+
+/* ---- one-call entry point ------------------------------------------------
+ * Replaces render() (renderer.hpp:16-18; called at main.cpp:104-106).
+ * Blocking.  Uploads the scene, renders w x h pixels on the current HIP
+ * device and copies the 4-byte/pixel framebuffer into host memory `rgb`
+ * (4*w*h bytes).  max_depth = 1 is the reference's behaviour; larger values
+ * enable the material bounces described at rt_material.                      */
+int gpu_render(const scene_desc *scene, const camera *cam, uint8_t *rgb, int w,
+               int h, int max_depth);
+
+/* As gpu_render, and also returns the per-pixel hit-id buffer (host, w*h
+ * int32, may be NULL) and the number of rays traced (may be NULL).  The id
+ * buffer is what calling check_intersection (renderer.hpp:21-23) with each
+ * pixel's primary ray yields.                                                */
+int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
+                   int32_t *hit_ids, uint64_t *n_rays, int w, int h,
+                   int max_depth);
+
+/* ---- resident scene + device-side rendering -------------------------------
+ * The `map(to: ...)` clause of renderer.cpp:13-21 as an explicit object: the
+ * flat arrays are uploaded once, re-laid-out for the kernels, and stay in HBM
+ * until rt_scene_destroy.                                                    */
+typedef struct rt_scene rt_scene;
+
+int rt_scene_create(const scene_desc *scene, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+
+typedef struct rt_frame {
+  uint8_t *dev_fb;      /* device, 4*w*h bytes, whole frame; required */
+  int32_t *dev_ids;     /* device, w*h int32, or NULL */
+  int32_t w, h;
+  int32_t max_depth;    /* >= 1 */
+  /* Row-band sharding (renderer.cpp:27-28 parallelises rows; here bands of
+   * band_rows rows are dealt round-robin): this call renders bands b with
+   * b % band_count == band_index.  band_count = 1 renders the whole frame.   */
+  int32_t band_rows;    /* rows per band, > 0 (ignored when band_count = 1) */
+  int32_t band_index;
+  int32_t band_count;
+  void *stream;         /* hipStream_t or NULL for the default stream */
+} rt_frame;
+
+/* Enqueues the render of `frame` on frame->stream and returns without
+ * waiting.  Pixels outside this call's bands are not touched.
+ * dev_ray_count (device uint64, or NULL) is incremented by the rays traced.  */
+int rt_render_device(rt_scene *scene, const camera *cam, const rt_frame *frame,
+                     uint64_t *dev_ray_count);
+
+/* Bulk form of check_intersection (renderer.hpp:21-23): n rays, host arrays.
+ * orig/dir are 3*n floats; kind (0 none / 1 triangle / 2 sphere), index
+ * (class-local, untouched semantics -> -1 on miss) are n int32; P is 3*n
+ * floats (hit point, unspecified on miss).                                   */
+int gpu_check_intersection(rt_scene *scene, int64_t n, const float *orig,
+                           const float *dir, int32_t *kind, int32_t *index,
+                           float *P);
+
+/* ---- misc ---------------------------------------------------------------- */
+const char *rt_last_error(void);
+int rt_device_count(void);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

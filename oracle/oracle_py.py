@@ -1,0 +1,248 @@
+"""ctypes doors onto the CPU checkers.  TEST INFRASTRUCTURE ONLY.
+
+  Oracle  -> oracle/liboracle.so      (our restatement, rt_oracle.c)
+  Ref     -> oracle/_ref/libref.so    (the real reference, built by oracle/Makefile)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "ray-tracer_amd", "python"))
+import rtamd  # noqa: E402  (struct definitions and the Scene container only)
+
+ORACLE_PATH = os.path.join(_HERE, "liboracle.so")
+REF_PATH = os.path.join(_HERE, "_ref", "libref.so")
+
+_f32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Oracle:
+    def __init__(self):
+        L = C.CDLL(ORACLE_PATH)
+        L.oracle_render.restype = C.c_uint64
+        L.oracle_render.argtypes = [C.POINTER(rtamd.SceneDesc), C.POINTER(rtamd.Camera),
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int]
+        L.oracle_check_intersection.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]
+        vp = C.c_void_p
+        L.oracle_length.restype = C.c_float
+        L.oracle_length.argtypes = [vp]
+        L.oracle_dot.restype = C.c_float
+        L.oracle_dot.argtypes = [vp, vp]
+        L.oracle_primary_ray.argtypes = [C.POINTER(rtamd.Camera), C.c_int, C.c_int, C.c_int,
+                                         C.c_int, vp, vp]
+        L.oracle_ray_sphere.argtypes = [vp, vp, vp, C.c_float, vp]
+        L.oracle_ray_triangle.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.oracle_normalize.argtypes = [vp]
+        L.oracle_normal.argtypes = [vp, vp, vp, vp]
+        L.oracle_reflect.argtypes = [vp, vp, vp]
+        L.oracle_refract.argtypes = [vp, vp, C.c_float, vp]
+        self.L = L
+
+    def render(self, scene: rtamd.Scene, w, h, max_depth=1, cam=None, rows=None,
+               want_ids=True):
+        """Returns (fb[h,w,4], ids[h,w] or None, n_rays).  rows=(begin,end,step)
+        renders a subset of rows; the rest of fb stays zero."""
+        cam = cam or rtamd.default_camera()
+        fb = np.zeros((h, w, 4), np.uint8)
+        ids = np.full((h, w), -2, np.int32) if want_ids else None
+        b, e, s = rows or (0, h, 1)
+        d = scene.desc()
+        n = self.L.oracle_render(C.byref(d), C.byref(cam), fb.ctypes.data,
+                                 ids.ctypes.data if want_ids else None, w, h, max_depth,
+                                 b, e, s)
+        return fb, ids, int(n)
+
+    def check_intersection(self, scene: rtamd.Scene, orig, dir):
+        orig = np.ascontiguousarray(orig, np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
+        n = len(orig)
+        kind = np.empty(n, np.int32)
+        index = np.full(n, -1, np.int32)
+        P = np.zeros((n, 3), np.float32)
+        d = scene.desc()
+        self.L.oracle_check_intersection_batch(
+            C.byref(d), C.c_long(n), C.c_void_p(orig.ctypes.data),
+            C.c_void_p(dir.ctypes.data), C.c_void_p(kind.ctypes.data),
+            C.c_void_p(index.ctypes.data), C.c_void_p(P.ctypes.data))
+        return kind, index, P
+
+    def primary_rays(self, w, h, pixels, cam=None):
+        """orig, dir for a list of (i, j) pixels."""
+        cam = cam or rtamd.default_camera()
+        o = np.zeros((len(pixels), 3), np.float32)
+        d = np.zeros((len(pixels), 3), np.float32)
+        for k, (i, j) in enumerate(pixels):
+            self.L.oracle_primary_ray(C.byref(cam), w, h, int(i), int(j),
+                                      o[k].ctypes.data, d[k].ctypes.data)
+        return o, d
+
+    # scalar math doors (known-answer tests)
+    def ray_sphere(self, orig, dir, centre, radius):
+        n = len(orig)
+        hit = np.zeros(n, np.int32)
+        P = np.zeros((n, 3), np.float32)
+        for i in range(n):
+            hit[i] = self.L.oracle_ray_sphere(orig[i].ctypes.data, dir[i].ctypes.data,
+                                              centre[i].ctypes.data, float(radius[i]),
+                                              P[i].ctypes.data)
+        return hit, P
+
+    def ray_triangle(self, orig, dir, tri):
+        n = len(orig)
+        hit = np.zeros(n, np.int32)
+        P = np.zeros((n, 3), np.float32)
+        for i in range(n):
+            t = tri[i]
+            hit[i] = self.L.oracle_ray_triangle(orig[i].ctypes.data, dir[i].ctypes.data,
+                                                t[0:3].ctypes.data, t[3:6].ctypes.data,
+                                                t[6:9].ctypes.data, P[i].ctypes.data)
+        return hit, P
+
+    def normalize(self, v):
+        v = np.array(v, np.float32).reshape(-1, 3).copy()
+        for i in range(len(v)):
+            self.L.oracle_normalize(v[i].ctypes.data)
+        return v
+
+    def normal(self, tri):
+        out = np.zeros((len(tri), 3), np.float32)
+        for i in range(len(tri)):
+            t = tri[i]
+            self.L.oracle_normal(t[0:3].ctypes.data, t[3:6].ctypes.data, t[6:9].ctypes.data,
+                                 out[i].ctypes.data)
+        return out
+
+    def reflect(self, d, n):
+        out = np.zeros_like(d)
+        for i in range(len(d)):
+            self.L.oracle_reflect(d[i].ctypes.data, n[i].ctypes.data, out[i].ctypes.data)
+        return out
+
+    def length(self, v):
+        return np.array([self.L.oracle_length(v[i].ctypes.data) for i in range(len(v))],
+                        np.float32)
+
+
+class Ref:
+    """The real reference.  Renders only at its compiled-in 2560x1440."""
+
+    def __init__(self):
+        L = C.CDLL(REF_PATH)
+        self.L = L
+        self.W = L.ref_canvas_width()
+        self.H = L.ref_canvas_height()
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_PATH)
+
+    def render(self, scene: rtamd.Scene, fov=90):
+        fb = np.zeros((self.H, self.W, 4), np.uint8)
+        self.L.ref_render(C.c_void_p(fb.ctypes.data), fov,
+                          C.c_void_p(scene.tris.ctypes.data),
+                          C.c_void_p(scene.color_tri.ctypes.data), scene.t_size,
+                          C.c_void_p(scene.spheres.ctypes.data),
+                          C.c_void_p(scene.radius.ctypes.data),
+                          C.c_void_p(scene.color_sphere.ctypes.data), scene.s_size,
+                          C.c_void_p(scene.lights.ctypes.data), scene.l_size)
+        return fb
+
+    def hit_ids(self, scene: rtamd.Scene, fov=90):
+        ids = np.zeros((self.H, self.W), np.int32)
+        self.L.ref_hit_ids(fov, C.c_void_p(scene.tris.ctypes.data), scene.t_size,
+                           C.c_void_p(scene.spheres.ctypes.data),
+                           C.c_void_p(scene.radius.ctypes.data), scene.s_size,
+                           C.c_void_p(ids.ctypes.data))
+        return ids
+
+    def check_intersection(self, scene: rtamd.Scene, orig, dir):
+        orig = np.ascontiguousarray(orig, np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
+        n = len(orig)
+        kind = np.empty(n, np.int32)
+        index = np.empty(n, np.int32)
+        P = np.zeros((n, 3), np.float32)
+        self.L.ref_check_intersection_batch(
+            C.c_long(n), C.c_void_p(scene.tris.ctypes.data), scene.t_size,
+            C.c_void_p(scene.spheres.ctypes.data), C.c_void_p(scene.radius.ctypes.data),
+            scene.s_size, C.c_void_p(orig.ctypes.data), C.c_void_p(dir.ctypes.data),
+            C.c_void_p(kind.ctypes.data), C.c_void_p(index.ctypes.data),
+            C.c_void_p(P.ctypes.data))
+        return kind, index, P
+
+    def ray_sphere(self, orig, dir, centre, radius):
+        n = len(orig)
+        hit = np.zeros(n, np.int32)
+        P = np.zeros((n, 3), np.float32)
+        self.L.ref_ray_sphere_batch(C.c_long(n), C.c_void_p(orig.ctypes.data),
+                                    C.c_void_p(dir.ctypes.data),
+                                    C.c_void_p(centre.ctypes.data),
+                                    C.c_void_p(radius.ctypes.data),
+                                    C.c_void_p(hit.ctypes.data), C.c_void_p(P.ctypes.data))
+        return hit, P
+
+    def ray_triangle(self, orig, dir, tri):
+        n = len(orig)
+        hit = np.zeros(n, np.int32)
+        P = np.zeros((n, 3), np.float32)
+        self.L.ref_ray_triangle_batch(C.c_long(n), C.c_void_p(orig.ctypes.data),
+                                      C.c_void_p(dir.ctypes.data),
+                                      C.c_void_p(tri.ctypes.data),
+                                      C.c_void_p(hit.ctypes.data), C.c_void_p(P.ctypes.data))
+        return hit, P
+
+    def normalize(self, v):
+        v = np.array(v, np.float32).reshape(-1, 3).copy()
+        self.L.ref_normalize_batch(C.c_long(len(v)), C.c_void_p(v.ctypes.data))
+        return v
+
+    def normal(self, tri):
+        out = np.zeros((len(tri), 3), np.float32)
+        self.L.ref_normal_batch(C.c_long(len(tri)), C.c_void_p(tri.ctypes.data),
+                                C.c_void_p(out.ctypes.data))
+        return out
+
+    def reflect(self, d, n):
+        out = np.zeros_like(d)
+        self.L.ref_reflect_batch(C.c_long(len(d)), C.c_void_p(d.ctypes.data),
+                                 C.c_void_p(n.ctypes.data), C.c_void_p(out.ctypes.data))
+        return out
+
+    def length(self, v):
+        out = np.zeros(len(v), np.float32)
+        self.L.ref_length_batch(C.c_long(len(v)), C.c_void_p(v.ctypes.data),
+                                C.c_void_p(out.ctypes.data))
+        return out
+
+    def init_spheres(self, row, col):
+        s = np.zeros((row * col, 3), np.float32)
+        r = np.zeros(row * col, np.float32)
+        c = np.zeros((row * col, 3), np.uint8)
+        n = self.L.ref_init_spheres(row, col, C.c_void_p(s.ctypes.data),
+                                    C.c_void_p(r.ctypes.data), C.c_void_p(c.ctypes.data))
+        assert n == row * col
+        return s, r, c
+
+    def read_scene(self, path):
+        nt, ns, nl = C.c_int(), C.c_int(), C.c_int()
+        self.L.ref_read_scene(path.encode(), C.byref(nt), C.byref(ns), C.byref(nl))
+        t = np.zeros((nt.value, 9), np.float32)
+        ct = np.zeros((nt.value, 3), np.uint8)
+        s = np.zeros((ns.value, 3), np.float32)
+        r = np.zeros(ns.value, np.float32)
+        cs = np.zeros((ns.value, 3), np.uint8)
+        l = np.zeros((nl.value, 3), np.float32)
+        self.L.ref_read_scene_copy(C.c_void_p(t.ctypes.data), C.c_void_p(ct.ctypes.data),
+                                   C.c_void_p(s.ctypes.data), C.c_void_p(r.ctypes.data),
+                                   C.c_void_p(cs.ctypes.data), C.c_void_p(l.ctypes.data))
+        return rtamd.Scene(t, ct, s, r, cs, l)
