@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the trace/shade path on N MI355X of one node.
+
+One "step" = one frame of the workload rendered through the C ABI
+(rt_render_device) with the scene already resident in HBM.  With N > 1 the
+frame's row bands are dealt round-robin to the ranks (one process per GPU) and
+the bands are gathered to rank 0 over RCCL inside the timed region; total work
+is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.  Ray counts come from the device-side counter.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "ray-tracer_amd", "python"))
+
+import rtamd  # noqa: E402
+
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32, FMA counted as 2 flop
+FLOP_PER_SPHERE_TEST = 25       # maths.cpp:126-133 up to the discriminant test
+FLOP_PER_TRIANGLE_TEST = 107    # maths.cpp:68-116 full path
+
+WORKLOADS = {
+    # name: (grid rows, grid cols, width, height, depth, materials)
+    "10k-spheres-4k-depth8": (100, 100, 3840, 2160, 8, True),
+    "10k-spheres-4k-depth1": (100, 100, 3840, 2160, 1, False),
+    "1k-spheres-1080p-depth4": (32, 32, 1920, 1080, 4, True),
+    "1k-spheres-1080p-depth1": (32, 32, 1920, 1080, 1, False),
+    "shipped-1440p-depth1": (10, 10, 2560, 1440, 1, False),
+}
+
+
+def build_scene(name):
+    row, col, w, h, depth, mats = WORKLOADS[name]
+    sc = rtamd.material_grid_scene(row, col) if mats else rtamd.grid_scene(row, col)
+    return sc, w, h, depth
+
+
+def cpu_baseline(sc, w, h, depth, budget_s=20.0):
+    """Times the CPU oracle (oracle/, the bit-exact restatement of the reference
+    renderer) on evenly spaced rows of the same frame, sized to ~budget_s."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from oracle_py import Oracle
+    o = Oracle()
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    # calibrate on a sparse sample, then size the real one
+    step0 = max(1, h // 32)
+    t = time.perf_counter()
+    _, _, n0 = o.render(sc, w, h, depth, rows=(step0 // 2, h, step0), want_ids=False)
+    dt0 = time.perf_counter() - t
+    rows0 = len(range(step0 // 2, h, step0))
+    per_row = dt0 / rows0
+    want_rows = int(min(h, max(rows0, budget_s / per_row)))
+    step = max(1, h // want_rows)
+    t = time.perf_counter()
+    _, _, n = o.render(sc, w, h, depth, rows=(step // 2, h, step), want_ids=False)
+    dt = time.perf_counter() - t
+    rows = len(range(step // 2, h, step))
+    return {
+        "value": n / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"every {step}th row ({rows} of {h} rows, {n} rays, {dt:.1f} s) of the same "
+                  f"{w}x{h} frame; oracle/rt_oracle.c, gcc -O2 -fopenmp -ffp-contract=off",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--band-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    name = args.workload or default_workload()
+    sc, w, h, depth = build_scene(name)
+    n_tests_per_ray = FLOP_PER_SPHERE_TEST * sc.s_size + FLOP_PER_TRIANGLE_TEST * sc.t_size
+
+    band_rows = args.band_rows
+    n_bands = (h + band_rows - 1) // band_rows
+    owned = list(range(rank, n_bands, world))
+    max_owned = (n_bands + world - 1) // world
+
+    fb = torch.zeros((n_bands * band_rows, w, 4), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ds = rtamd.DeviceScene(sc)
+    fb_bands = fb.view(n_bands, band_rows * w * 4)
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty((max_owned, band_rows * w * 4), dtype=torch.uint8, device=dev)
+                       for _ in range(world)]
+    send = torch.zeros((max_owned, band_rows * w * 4), dtype=torch.uint8, device=dev)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    kernel_ms = []
+
+    def step(timed):
+        if timed:
+            ev0.record()
+        ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth, band_rows=band_rows,
+                         band_index=rank, band_count=world, stream=stream,
+                         dev_ray_count=cnt.data_ptr())
+        if timed:
+            ev1.record()
+        if world > 1:
+            send[:len(owned)].copy_(fb_bands[rank::world])
+            dist.gather(send, gather_list, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    k = len(range(r, n_bands, world))
+                    fb_bands[r::world].copy_(gather_list[r][:k])
+        if timed:
+            ev1.synchronize()
+            kernel_ms.append(ev0.elapsed_time(ev1))
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    cnt.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    rays = cnt.clone()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_rays = int(rays.item())
+    dt = float(tmax.item())
+
+    if rank == 0:
+        value = total_rays / dt / 1e6
+        # roofline of the dominant kernel (k_render) on this rank: algorithmic
+        # FLOP of the rays this rank traced per launch / mean launch duration
+        my_rays_per_launch = int(cnt.item()) / args.steps
+        k_ms = float(np.mean(kernel_ms))
+        achieved = my_rays_per_launch * n_tests_per_ray / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": name, "width": w, "height": h, "max_depth": depth,
+                       "spheres": sc.s_size, "triangles": sc.t_size, "lights": sc.l_size,
+                       "materials": sc.mat_sphere is not None,
+                       "rays_per_frame": total_rays // args.steps,
+                       "sharding": f"row bands of {band_rows}, round-robin over {world} GPU(s)"},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved,
+                         "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "k_render", "kernel_ms": k_ms,
+                         "flop_per_ray": n_tests_per_ray,
+                         "note": "algorithmic FLOP = rays x (25 x spheres + 107 x triangles); "
+                                 "parity forbids FMA, so 1 flop/lane/instr caps executed "
+                                 "arithmetic at 1/2 of peak"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, w, h, depth)
+        print(json.dumps(out))
+    ds.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def default_workload():
+    return "10k-spheres-4k-depth1"
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,395 @@
+// rt_api.hip — the C ABI of include/rt_amd.h on top of the kernels.
+//
+// Host-side only: argument checks, HBM residency of the scene (the explicit
+// form of the `map(to:)` clause at renderer.cpp:13-21), launch geometry and the
+// copy-back of the framebuffer (`map(from:)`, renderer.cpp:22-25).  There is no
+// CPU rendering path in this library: if HIP is unusable every entry point
+// fails with an error code.
+#include "../../include/rt_amd.h"
+#include "rt_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess)                                                      \
+      return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                  \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                  \
+  } while (0)
+
+template <typename T> struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0)
+      return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  void release() {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+} // namespace
+
+struct rt_scene {
+  int device = 0;
+  int t_size = 0, s_size = 0, s_pad = 0, l_size = 0;
+  DevBuf<float4> sph_geo, sph_prim, lights, mat_tri, mat_sph;
+  DevBuf<rt::TriRec> tri;
+  DevBuf<uchar4> col_tri, col_sph;
+  bool has_mat_tri = false, has_mat_sph = false;
+  bool eye_valid = false;
+  float eye[3] = {0, 0, 0};
+
+  rt::SceneDev dev() const {
+    rt::SceneDev d;
+    d.sph_geo = sph_geo.p;
+    d.sph_prim = sph_prim.p;
+    d.tri = tri.p;
+    d.col_tri = col_tri.p;
+    d.col_sph = col_sph.p;
+    d.mat_tri = has_mat_tri ? mat_tri.p : nullptr;
+    d.mat_sph = has_mat_sph ? mat_sph.p : nullptr;
+    d.lights = lights.p;
+    d.t_size = t_size;
+    d.s_size = s_size;
+    d.s_pad = s_pad;
+    d.l_size = l_size;
+    return d;
+  }
+};
+
+namespace {
+
+int check_scene_desc(const scene_desc *s) {
+  if (!s)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  if (s->t_size < 0 || s->s_size < 0 || s->l_size < 0)
+    return fail(RT_ERR_BAD_ARG, "negative primitive or light count");
+  if (s->t_size > 0 && (!s->tris || !s->color_tri))
+    return fail(RT_ERR_BAD_ARG, "t_size > 0 but tris/color_tri is NULL");
+  if (s->s_size > 0 && (!s->spheres || !s->radius || !s->color_sphere))
+    return fail(RT_ERR_BAD_ARG, "s_size > 0 but spheres/radius/color_sphere is NULL");
+  if (s->l_size > 0 && !s->lights)
+    return fail(RT_ERR_BAD_ARG, "l_size > 0 but lights is NULL");
+  return RT_OK;
+}
+
+int ensure_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(RT_ERR_NO_DEVICE, "no HIP device: %s",
+                e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+  return RT_OK;
+}
+
+template <typename T>
+int upload(DevBuf<T> &dst, const void *src, size_t count) {
+  HIP_TRY(dst.alloc(count));
+  if (count)
+    HIP_TRY(hipMemcpy(dst.p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+int scene_build(rt_scene *S, const scene_desc *s) {
+  HIP_TRY(hipGetDevice(&S->device));
+  S->t_size = s->t_size;
+  S->s_size = s->s_size;
+  S->l_size = s->l_size;
+  S->s_pad = (s->s_size + rt::SPH_UNROLL - 1) / rt::SPH_UNROLL * rt::SPH_UNROLL;
+
+  // staging copies of the flat arrays; freed when this function returns
+  DevBuf<float> tris, spheres, radius;
+  DevBuf<uint8_t> ctri, csph;
+  int rc;
+  if ((rc = upload(tris, s->tris, (size_t)9 * s->t_size)) ||
+      (rc = upload(ctri, s->color_tri, (size_t)3 * s->t_size)) ||
+      (rc = upload(spheres, s->spheres, (size_t)3 * s->s_size)) ||
+      (rc = upload(radius, s->radius, (size_t)s->s_size)) ||
+      (rc = upload(csph, s->color_sphere, (size_t)3 * s->s_size)))
+    return rc;
+
+  HIP_TRY(S->sph_geo.alloc(S->s_pad));
+  HIP_TRY(S->sph_prim.alloc(S->s_pad));
+  HIP_TRY(S->tri.alloc(S->t_size));
+  HIP_TRY(S->col_tri.alloc(S->t_size));
+  HIP_TRY(S->col_sph.alloc(S->s_size));
+
+  // lights as float4
+  {
+    float4 *tmp = new (std::nothrow) float4[S->l_size > 0 ? S->l_size : 1];
+    if (!tmp)
+      return fail(RT_ERR_HIP, "out of host memory");
+    for (int l = 0; l < S->l_size; l++)
+      tmp[l] = make_float4(s->lights[3 * l], s->lights[3 * l + 1],
+                           s->lights[3 * l + 2], 0.f);
+    rc = upload(S->lights, tmp, (size_t)S->l_size);
+    delete[] tmp;
+    if (rc)
+      return rc;
+  }
+  static_assert(sizeof(rt_material) == sizeof(float4), "material is one float4");
+  S->has_mat_tri = s->mat_tri != nullptr && s->t_size > 0;
+  S->has_mat_sph = s->mat_sphere != nullptr && s->s_size > 0;
+  if (S->has_mat_tri && (rc = upload(S->mat_tri, s->mat_tri, (size_t)s->t_size)))
+    return rc;
+  if (S->has_mat_sph && (rc = upload(S->mat_sph, s->mat_sphere, (size_t)s->s_size)))
+    return rc;
+
+  rt::PrepArgs a;
+  a.tris = tris.p;
+  a.color_tri = ctri.p;
+  a.spheres = spheres.p;
+  a.radius = radius.p;
+  a.color_sphere = csph.p;
+  a.t_size = S->t_size;
+  a.s_size = S->s_size;
+  a.s_pad = S->s_pad;
+  a.sph_geo = S->sph_geo.p;
+  a.tri = S->tri.p;
+  a.col_tri = S->col_tri.p;
+  a.col_sph = S->col_sph.p;
+  HIP_TRY(rt::launch_prep_scene(a, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr)); // staging buffers die here
+  S->eye_valid = false;
+  return RT_OK;
+}
+
+// Eye-relative records are rebuilt only when the eye moves.
+int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
+  if (S->eye_valid && memcmp(S->eye, cam->origin, sizeof S->eye) == 0)
+    return RT_OK;
+  rt::EyeArgs a;
+  a.sph_geo = S->sph_geo.p;
+  a.sph_prim = S->sph_prim.p;
+  a.tri = S->tri.p;
+  a.t_size = S->t_size;
+  a.s_size = S->s_size;
+  a.s_pad = S->s_pad;
+  a.ox = cam->origin[0];
+  a.oy = cam->origin[1];
+  a.oz = cam->origin[2];
+  HIP_TRY(rt::launch_prep_eye(a, st));
+  memcpy(S->eye, cam->origin, sizeof S->eye);
+  S->eye_valid = true;
+  return RT_OK;
+}
+
+rt::CameraDev camera_dev(const camera *cam, int w, int h) {
+  rt::CameraDev c;
+  c.tan_half = tan(cam->fov_deg * 0.5 * M_PI / 180); // renderer.cpp:35
+  c.aspect = (float)w / (float)h;                     // renderer.cpp:11
+  c.ox = cam->origin[0];
+  c.oy = cam->origin[1];
+  c.oz = cam->origin[2];
+  c.plane_z = cam->plane_z;
+  return c;
+}
+
+} // namespace
+
+extern "C" {
+
+void rt_camera_default(camera *cam) {
+  if (!cam)
+    return;
+  cam->fov_deg = 90;     // main.cpp:88
+  cam->origin[0] = 0.0f; // renderer.cpp:39
+  cam->origin[1] = 0.0f;
+  cam->origin[2] = 1.0f;
+  cam->plane_z = -1.0f;  // renderer.cpp:38
+}
+
+const char *rt_last_error(void) { return g_err; }
+
+const char *rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int rt_scene_create(const scene_desc *scene, rt_scene **out) {
+  if (!out)
+    return fail(RT_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  int rc;
+  if ((rc = check_scene_desc(scene)) || (rc = ensure_device()))
+    return rc;
+  rt_scene *S = new (std::nothrow) rt_scene;
+  if (!S)
+    return fail(RT_ERR_HIP, "out of host memory");
+  rc = scene_build(S, scene);
+  if (rc) {
+    delete S;
+    return rc;
+  }
+  *out = S;
+  return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *scene) { delete scene; }
+
+int rt_render_device(rt_scene *S, const camera *cam, const rt_frame *fr,
+                     uint64_t *dev_ray_count) {
+  if (!S || !cam || !fr)
+    return fail(RT_ERR_BAD_ARG, "scene, camera or frame is NULL");
+  if (!fr->dev_fb)
+    return fail(RT_ERR_BAD_ARG, "frame.dev_fb is NULL");
+  if (fr->w <= 0 || fr->h <= 0)
+    return fail(RT_ERR_BAD_ARG, "frame size %dx%d", fr->w, fr->h);
+  if (fr->max_depth < 1)
+    return fail(RT_ERR_BAD_ARG, "max_depth %d < 1", fr->max_depth);
+  int band_count = fr->band_count < 1 ? 1 : fr->band_count;
+  int band_rows = band_count == 1 ? 8 : fr->band_rows;
+  if (band_rows <= 0 || (band_rows & 7))
+    return fail(RT_ERR_BAD_ARG, "band_rows %d must be a positive multiple of 8",
+                band_rows);
+  if (fr->band_index < 0 || fr->band_index >= band_count)
+    return fail(RT_ERR_BAD_ARG, "band_index %d outside [0,%d)", fr->band_index,
+                band_count);
+  if (fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph))
+    return fail(RT_ERR_UNSUPPORTED, "material bounces are not built yet");
+  hipStream_t st = (hipStream_t)fr->stream;
+  HIP_TRY(hipSetDevice(S->device));
+  int rc = scene_set_eye(S, cam, st);
+  if (rc)
+    return rc;
+
+  rt::FrameDev f;
+  f.fb = fr->dev_fb;
+  f.ids = fr->dev_ids;
+  f.ray_count = dev_ray_count;
+  f.w = fr->w;
+  f.h = fr->h;
+  f.max_depth = fr->max_depth;
+  f.band_rows = band_rows;
+  f.band_index = fr->band_index;
+  f.band_count = band_count;
+  int bands_total = (fr->h + band_rows - 1) / band_rows;
+  int owned = bands_total > fr->band_index
+                  ? (bands_total - fr->band_index + band_count - 1) / band_count
+                  : 0;
+  HIP_TRY(rt::launch_render(S->dev(), camera_dev(cam, fr->w, fr->h), f,
+                            owned * (band_rows / 8), st));
+  return RT_OK;
+}
+
+int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
+                   int32_t *hit_ids, uint64_t *n_rays, int w, int h,
+                   int max_depth) {
+  if (!cam || !rgb)
+    return fail(RT_ERR_BAD_ARG, "camera or output buffer is NULL");
+  if (w <= 0 || h <= 0)
+    return fail(RT_ERR_BAD_ARG, "frame size %dx%d", w, h);
+  rt_scene *S = nullptr;
+  int rc = rt_scene_create(scene, &S);
+  if (rc)
+    return rc;
+  size_t npx = (size_t)w * h;
+  DevBuf<uint8_t> fb;
+  DevBuf<int32_t> ids;
+  DevBuf<uint64_t> cnt;
+  auto body = [&]() -> int {
+    HIP_TRY(fb.alloc(npx * 4));
+    if (hit_ids)
+      HIP_TRY(ids.alloc(npx));
+    HIP_TRY(cnt.alloc(1));
+    HIP_TRY(hipMemset(cnt.p, 0, sizeof(uint64_t)));
+    rt_frame fr;
+    memset(&fr, 0, sizeof fr);
+    fr.dev_fb = fb.p;
+    fr.dev_ids = ids.p;
+    fr.w = w;
+    fr.h = h;
+    fr.max_depth = max_depth;
+    fr.band_rows = 8;
+    fr.band_index = 0;
+    fr.band_count = 1;
+    fr.stream = nullptr;
+    int r = rt_render_device(S, cam, &fr, cnt.p);
+    if (r)
+      return r;
+    HIP_TRY(hipMemcpy(rgb, fb.p, npx * 4, hipMemcpyDeviceToHost));
+    if (hit_ids)
+      HIP_TRY(hipMemcpy(hit_ids, ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_rays)
+      HIP_TRY(hipMemcpy(n_rays, cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+  };
+  rc = body();
+  rt_scene_destroy(S);
+  return rc;
+}
+
+int gpu_render(const scene_desc *scene, const camera *cam, uint8_t *rgb, int w,
+               int h, int max_depth) {
+  return gpu_render_ids(scene, cam, rgb, nullptr, nullptr, w, h, max_depth);
+}
+
+int gpu_check_intersection(rt_scene *S, int64_t n, const float *orig,
+                           const float *dir, int32_t *kind, int32_t *index,
+                           float *P) {
+  if (!S)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  if (n < 0)
+    return fail(RT_ERR_BAD_ARG, "n < 0");
+  if (n == 0)
+    return RT_OK;
+  if (!orig || !dir || !kind || !index || !P)
+    return fail(RT_ERR_BAD_ARG, "NULL ray or result array");
+  HIP_TRY(hipSetDevice(S->device));
+  DevBuf<float> d_o, d_d, d_P;
+  DevBuf<int32_t> d_k, d_i;
+  int rc;
+  if ((rc = upload(d_o, orig, (size_t)3 * n)) || (rc = upload(d_d, dir, (size_t)3 * n)))
+    return rc;
+  HIP_TRY(d_P.alloc((size_t)3 * n));
+  HIP_TRY(d_k.alloc((size_t)n));
+  HIP_TRY(d_i.alloc((size_t)n));
+  rt::CheckArgs a;
+  a.n = (long)n;
+  a.orig = d_o.p;
+  a.dir = d_d.p;
+  a.kind = d_k.p;
+  a.index = d_i.p;
+  a.P = d_P.p;
+  HIP_TRY(rt::launch_check(S->dev(), a, nullptr));
+  HIP_TRY(hipMemcpy(kind, d_k.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(index, d_i.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(P, d_P.p, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+} // extern "C"

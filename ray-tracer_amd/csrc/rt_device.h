@@ -1,0 +1,312 @@
+// rt_device.h — device-side scene layout and the per-ray math of the path.
+//
+// Everything here must reproduce the reference's UNFUSED binary32/binary64
+// arithmetic in source order (this translation unit is compiled with
+// -ffp-contract=off; never -ffast-math).  Comments cite the reference line each
+// expression follows.  Where work is hoisted (per-ray `a`, per-sphere r*r, the
+// triangle normal) the hoisted value is computed by the same operations in the
+// same order, so the bits are the same.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// ---- layout in HBM ----------------------------------------------------------
+// Spheres, two 16-byte records per sphere (structure of arrays):
+//   geo[i]  = (cx, cy, cz, r*r)                      any ray
+//   prim[i] = (Lx, Ly, Lz, c) with L = eye - centre,  rays leaving the eye
+//             c = L.L - r*r  (maths.cpp:126,129)
+// Both arrays are padded to a multiple of SPH_UNROLL with records that can
+// never pass the discriminant test.
+// Triangles, seven float4 per triangle (TriRec): unit normal N and d = N.p1
+// (maths.cpp:69,77), the corners, the three edge vectors (maths.cpp:92,101,110)
+// and N.eye for rays leaving the eye (maths.cpp:78).
+struct TriRec {
+  float4 n_d;   // N.xyz, d
+  float4 p1_no; // p1.xyz, N.eye
+  float4 p2;    // p2.xyz
+  float4 p3;    // p3.xyz
+  float4 e0;    // p2 - p1
+  float4 e1;    // p3 - p2
+  float4 e2;    // p1 - p3
+};
+
+constexpr int SPH_UNROLL = 4;
+
+struct SceneDev {
+  const float4 *sph_geo;
+  const float4 *sph_prim;
+  const TriRec *tri;
+  const uchar4 *col_tri;
+  const uchar4 *col_sph;
+  const float4 *mat_tri; // (kr, kt, ior, 0) or nullptr
+  const float4 *mat_sph;
+  const float4 *lights;  // xyz
+  int t_size, s_size, s_pad, l_size;
+};
+
+struct CameraDev {
+  double tan_half; // tan(fov*0.5*M_PI/180), evaluated on the host (renderer.cpp:35)
+  float aspect;    // (float)w/(float)h (renderer.cpp:11)
+  float ox, oy, oz;
+  float plane_z;
+};
+
+#define RT_INF __builtin_huge_valf()
+
+// ---- maths.cpp helpers ------------------------------------------------------
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx,
+                                      float by, float bz) {
+  return ax * bx + ay * by + az * bz; // maths.cpp:54-56, left to right
+}
+
+__device__ __forceinline__ float length3(float x, float y, float z) {
+  return sqrtf(x * x + y * y + z * z); // maths.cpp:23-25
+}
+
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
+  float l = length3(x, y, z); // maths.cpp:27-37
+  if (l == 0.0f)
+    return;
+  x /= l;
+  y /= l;
+  z /= l;
+}
+
+// maths.cpp:163-168
+__device__ __forceinline__ void reflect3(float dx, float dy, float dz, float nx,
+                                         float ny, float nz, float &rx,
+                                         float &ry, float &rz) {
+  float k = -2.0f * dot3(dx, dy, dz, nx, ny, nz);
+  rx = nx * k + dx;
+  ry = ny * k + dy;
+  rz = nz * k + dz;
+}
+
+// Unit normal of a triangle exactly as maths.cpp:39-46 (sub, sub, cross,
+// normalize).  Used once per triangle at scene upload.
+__device__ __forceinline__ void tri_normal(const float *p1, const float *p2,
+                                           const float *p3, float &nx,
+                                           float &ny, float &nz) {
+  float ax = p2[0] - p1[0], ay = p2[1] - p1[1], az = p2[2] - p1[2];
+  float bx = p3[0] - p1[0], by = p3[1] - p1[1], bz = p3[2] - p1[2];
+  nx = ay * bz - az * by; // maths.cpp:48-52
+  ny = az * bx - ax * bz;
+  nz = ax * by - ay * bx;
+  normalize3(nx, ny, nz);
+}
+
+// ---- ray / sphere, the part after the discriminant screen --------------------
+// maths.cpp:132-158 given a, b, c of maths.cpp:127-129 and the two products
+// bb = b*b, ac = (4*a)*c of maths.cpp:132.  Returns true and P on a hit.
+__device__ __forceinline__ bool sphere_finish(float a, float b, float c,
+                                              float bb, float ac, float ox,
+                                              float oy, float oz, float dx,
+                                              float dy, float dz, float &Px,
+                                              float &Py, float &Pz) {
+  const float eps = 0.001f; // (float)0.001, maths.cpp:124
+  float discr = bb - ac;
+  float t0, t1;
+  if (discr < 0) {
+    return false;
+  } else if (discr == 0) {
+    t0 = t1 = (float)(-0.5 * (double)b / (double)a); // maths.cpp:136, double
+  } else {
+    // maths.cpp:138-141.  -0.5 * x is an exact scaling, so the double product
+    // rounded to float equals the float product.
+    float sq = sqrtf(discr);
+    float q = (b > eps) ? -0.5f * (b + sq) : -0.5f * (b - sq);
+    t0 = q / a;
+    t1 = c / q;
+  }
+  if (t0 >= t1) { // maths.cpp:144-145
+    float tmp = t1;
+    t1 = t0;
+    t0 = tmp;
+  }
+  if (t0 <= eps) { // maths.cpp:147-152
+    t0 = t1;
+    if (t0 <= eps)
+      return false;
+  }
+  Px = ox + dx * t0; // maths.cpp:154-158
+  Py = oy + dy * t0;
+  Pz = oz + dz * t0;
+  return true;
+}
+
+// ---- ray / triangle from the precomputed record -------------------------------
+// maths.cpp:64-119.  `no` is N.orig (maths.cpp:78).
+__device__ __forceinline__ bool triangle_test(const TriRec &T, float no,
+                                              float ox, float oy, float oz,
+                                              float dx, float dy, float dz,
+                                              float &Px, float &Py, float &Pz) {
+  const float eps = 0.0001f; // (float)0.0001, maths.cpp:66
+  const float nx = T.n_d.x, ny = T.n_d.y, nz = T.n_d.z;
+  float nd = dot3(nx, ny, nz, dx, dy, dz);
+  if (fabsf(nd) < eps)
+    return false;
+  float t = (no + T.n_d.w) / nd; // maths.cpp:78 (sic: N.orig + d)
+  if (t < 0)
+    return false;
+  Px = ox + dx * t; // maths.cpp:83-87
+  Py = oy + dy * t;
+  Pz = oz + dz * t;
+  {
+    float vx = Px - T.p1_no.x, vy = Py - T.p1_no.y, vz = Pz - T.p1_no.z;
+    float cx = T.e0.y * vz - T.e0.z * vy; // maths.cpp:95
+    float cy = T.e0.z * vx - T.e0.x * vz;
+    float cz = T.e0.x * vy - T.e0.y * vx;
+    if (dot3(nx, ny, nz, cx, cy, cz) < 0)
+      return false;
+  }
+  {
+    float vx = Px - T.p2.x, vy = Py - T.p2.y, vz = Pz - T.p2.z;
+    float cx = T.e1.y * vz - T.e1.z * vy; // maths.cpp:104
+    float cy = T.e1.z * vx - T.e1.x * vz;
+    float cz = T.e1.x * vy - T.e1.y * vx;
+    if (dot3(nx, ny, nz, cx, cy, cz) < 0)
+      return false;
+  }
+  {
+    float vx = Px - T.p3.x, vy = Py - T.p3.y, vz = Pz - T.p3.z;
+    float cx = T.e2.y * vz - T.e2.z * vy; // maths.cpp:113
+    float cy = T.e2.z * vx - T.e2.x * vz;
+    float cz = T.e2.x * vy - T.e2.y * vx;
+    if (dot3(nx, ny, nz, cx, cy, cz) < 0)
+      return false;
+  }
+  return true;
+}
+
+// ---- check_intersection (renderer.cpp:145-193) ---------------------------------
+// One lane = one ray; the primitive being tested is the same for every lane of
+// the wave, so its record is read through wave-uniform (scalar) loads and the
+// per-lane work is the reference's arithmetic only.
+//
+// FROM_EYE: the ray starts at the camera eye, so L, c (spheres) and N.orig
+//           (triangles) come precomputed from the scene records.
+// ANY_HIT : only "is anything hit" is wanted (shadow rays, renderer.cpp:119);
+//           the loop may stop as soon as every live lane has a hit, which
+//           cannot change the answer.
+//
+// Nearest is by |P| from the WORLD origin with strict '>' (lowest index wins in
+// a class); between classes a triangle wins ties ('<=', renderer.cpp:181).  A
+// candidate whose |P| is not below +inf is never accepted (renderer.cpp:159,170
+// with the FLT_MAX start value), which also keeps NaNs out.
+struct Hit {
+  int kind;  // 0 none, 1 triangle, 2 sphere
+  int index; // class-local
+  float Px, Py, Pz;
+};
+
+template <bool FROM_EYE, bool ANY_HIT>
+__device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
+                                     float oy, float oz, float dx, float dy,
+                                     float dz) {
+  float len_t = RT_INF, len_s = RT_INF;
+  int idx_t = -1, idx_s = -1;
+  float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
+
+  // ---- triangles, renderer.cpp:156-166 ----
+  for (int i = 0; i < sc.t_size; i++) {
+    const TriRec &T = sc.tri[i];
+    float no = FROM_EYE ? T.p1_no.w
+                        : dot3(T.n_d.x, T.n_d.y, T.n_d.z, ox, oy, oz);
+    float Px, Py, Pz;
+    if (live && triangle_test(T, no, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
+      float len = length3(Px, Py, Pz);
+      if (len_t > len) {
+        len_t = len;
+        idx_t = i;
+        tPx = Px;
+        tPy = Py;
+        tPz = Pz;
+      }
+    }
+    if (ANY_HIT && !__any(live && idx_t < 0))
+      break;
+  }
+
+  // ---- spheres, renderer.cpp:168-177 ----
+  const float a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
+  const float a4 = 4.0f * a;                    // maths.cpp:132, (4*a)*c
+  const float4 *__restrict__ rec = FROM_EYE ? sc.sph_prim : sc.sph_geo;
+  bool seek = live && !(ANY_HIT && idx_t >= 0);
+  if (!ANY_HIT || __any(seek)) {
+    for (int i = 0; i < sc.s_pad; i += SPH_UNROLL) {
+      float b[SPH_UNROLL], c[SPH_UNROLL], bb[SPH_UNROLL], ac[SPH_UNROLL];
+      bool any_cand = false;
+#pragma unroll
+      for (int u = 0; u < SPH_UNROLL; u++) {
+        const float4 s = rec[i + u];
+        float Lx, Ly, Lz;
+        if (FROM_EYE) {
+          Lx = s.x;
+          Ly = s.y;
+          Lz = s.z;
+          c[u] = s.w;
+        } else {
+          Lx = ox - s.x; // maths.cpp:126
+          Ly = oy - s.y;
+          Lz = oz - s.z;
+          c[u] = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - s.w; // maths.cpp:129
+        }
+        b[u] = 2.0f * dot3(dx, dy, dz, Lx, Ly, Lz); // maths.cpp:128
+        bb[u] = b[u] * b[u];
+        ac[u] = a4 * c[u];
+        // maths.cpp:132-133: discr = bb - ac is negative exactly when bb < ac
+        // (a float difference has the sign of the exact difference).
+        any_cand |= !(bb[u] < ac[u]);
+      }
+      if (any_cand) {
+#pragma unroll
+        for (int u = 0; u < SPH_UNROLL; u++) {
+          if (seek && !(bb[u] < ac[u]) && (i + u) < sc.s_size) {
+            float Px, Py, Pz;
+            if (sphere_finish(a, b[u], c[u], bb[u], ac[u], ox, oy, oz, dx, dy,
+                              dz, Px, Py, Pz)) {
+              float len = length3(Px, Py, Pz);
+              if (len_s > len) { // renderer.cpp:170, strict
+                len_s = len;
+                idx_s = i + u;
+                sPx = Px;
+                sPy = Py;
+                sPz = Pz;
+                if (ANY_HIT)
+                  seek = false;
+              }
+            }
+          }
+        }
+        if (ANY_HIT && !__any(seek))
+          break;
+      }
+    }
+  }
+
+  // ---- renderer.cpp:179-192 ----
+  Hit h;
+  h.kind = 0;
+  h.index = -1;
+  h.Px = h.Py = h.Pz = 0;
+  if (idx_t < 0 && idx_s < 0)
+    return h;
+  if (len_t <= len_s) {
+    h.kind = 1;
+    h.index = idx_t;
+    h.Px = tPx;
+    h.Py = tPy;
+    h.Pz = tPz;
+  } else if (len_t > len_s) {
+    h.kind = 2;
+    h.index = idx_s;
+    h.Px = sPx;
+    h.Py = sPy;
+    h.Pz = sPz;
+  }
+  return h;
+}
+
+} // namespace rt

@@ -1,0 +1,55 @@
+// rt_kernels.h — argument blocks and host launchers of the kernels in
+// rt_kernels.hip.  Internal to the library (not part of the C ABI).
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+struct PrepArgs {
+  // inputs: the reference's flat arrays, already in device memory
+  const float *tris;
+  const uint8_t *color_tri;
+  const float *spheres;
+  const float *radius;
+  const uint8_t *color_sphere;
+  int t_size, s_size, s_pad;
+  // outputs
+  float4 *sph_geo;
+  TriRec *tri;
+  uchar4 *col_tri;
+  uchar4 *col_sph;
+};
+
+struct EyeArgs {
+  const float4 *sph_geo;
+  float4 *sph_prim;
+  TriRec *tri;
+  int t_size, s_size, s_pad;
+  float ox, oy, oz;
+};
+
+struct FrameDev {
+  uint8_t *fb;   // 4 bytes per pixel, whole frame
+  int32_t *ids;  // or nullptr
+  uint64_t *ray_count; // or nullptr
+  int w, h;
+  int max_depth;
+  int band_rows, band_index, band_count;
+};
+
+struct CheckArgs {
+  long n;
+  const float *orig;
+  const float *dir;
+  int32_t *kind;
+  int32_t *index;
+  float *P;
+};
+
+hipError_t launch_prep_scene(const PrepArgs &a, hipStream_t st);
+hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st);
+hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
+                         const FrameDev &f, int owned_tile_rows, hipStream_t st);
+hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);
+
+} // namespace rt

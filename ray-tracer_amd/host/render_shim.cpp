@@ -1,0 +1,114 @@
+// render_shim.cpp — the reference's two renderer entry points, same names,
+// same C++ signatures (renderer.hpp:16-18 and renderer.hpp:21-23), implemented
+// on the GPU library.  A host program written against the reference's
+// renderer.hpp (its main.cpp:104-106 starts `render` on a std::thread) links
+// against librt_shim.so instead of renderer.o + maths.o and needs no source
+// change.
+//
+// The frame size is a compile-time constant in the reference
+// (renderer.hpp:10-11) and the caller allocates 4*W*H bytes from the same
+// constants (main.cpp:91), so the shim is built for one size:
+// -DRT_CANVAS_WIDTH / -DRT_CANVAS_HEIGHT, default 2560 x 1440.
+//
+// render() returns void in the reference and cannot report failure
+// (renderer.cpp:7); on a GPU error the shim writes the reason to stderr and
+// leaves the frame black with alpha 255, which is what the reference's pixel
+// initialisation (renderer.cpp:50-53) produces before anything is shaded.
+#include "../../include/rt_amd.h"
+
+#include <cstdio>
+#include <cstring>
+
+#ifndef RT_CANVAS_WIDTH
+#define RT_CANVAS_WIDTH 2560
+#endif
+#ifndef RT_CANVAS_HEIGHT
+#define RT_CANVAS_HEIGHT 1440
+#endif
+
+static scene_desc pack(float *tris, unsigned char *color_tri, int t_size,
+                       float *spheres, float *radius,
+                       unsigned char *color_sphere, int s_size, float *lights,
+                       int l_size) {
+  scene_desc s;
+  memset(&s, 0, sizeof s);
+  s.tris = tris;
+  s.color_tri = color_tri;
+  s.t_size = t_size;
+  s.spheres = spheres;
+  s.radius = radius;
+  s.color_sphere = color_sphere;
+  s.s_size = s_size;
+  s.lights = lights;
+  s.l_size = l_size;
+  return s;
+}
+
+void render(unsigned char *frameBuffer, int fov, float *tris,
+            unsigned char *color_tri, int t_size, float *spheres, float *radius,
+            unsigned char *color_sphere, int s_size, float *lights,
+            int l_size) {
+  scene_desc s = pack(tris, color_tri, t_size, spheres, radius, color_sphere,
+                      s_size, lights, l_size);
+  camera cam;
+  rt_camera_default(&cam);
+  cam.fov_deg = fov;
+  int rc = gpu_render(&s, &cam, frameBuffer, RT_CANVAS_WIDTH, RT_CANVAS_HEIGHT, 1);
+  if (rc != RT_OK) {
+    fprintf(stderr, "render: GPU path failed (%d): %s\n", rc, rt_last_error());
+    if (frameBuffer) {
+      const size_t n = (size_t)RT_CANVAS_WIDTH * RT_CANVAS_HEIGHT;
+      for (size_t p = 0; p < n; p++) {
+        frameBuffer[4 * p + 0] = 0;
+        frameBuffer[4 * p + 1] = 0;
+        frameBuffer[4 * p + 2] = 0;
+        frameBuffer[4 * p + 3] = 255;
+      }
+    }
+  }
+}
+
+// One ray per call, as the reference's signature demands.  Correct, and slow by
+// construction (a scene upload and a kernel launch per ray): bulk callers use
+// gpu_check_intersection.  *index is left untouched on a miss, as in
+// renderer.cpp:179-180.
+int check_intersection(float *tris, int t_size, float *spheres, float *radius,
+                       int s_size, float *P, int *index, float *orig,
+                       float *dir) {
+  scene_desc s = pack(tris, nullptr, t_size, spheres, radius, nullptr, s_size,
+                      nullptr, 0);
+  // colours play no part in a geometric query; give the upload zeros to read
+  unsigned char *ct = nullptr, *cs = nullptr;
+  if (t_size > 0) {
+    ct = new unsigned char[3 * (size_t)t_size]();
+    s.color_tri = ct;
+  }
+  if (s_size > 0) {
+    cs = new unsigned char[3 * (size_t)s_size]();
+    s.color_sphere = cs;
+  }
+  rt_scene *S = nullptr;
+  int kind = 0;
+  int rc = rt_scene_create(&s, &S);
+  if (rc == RT_OK) {
+    int32_t k = 0, idx = -1;
+    float p[3] = {0, 0, 0};
+    rc = gpu_check_intersection(S, 1, orig, dir, &k, &idx, p);
+    if (rc == RT_OK) {
+      kind = k;
+      if (k != 0) {
+        P[0] = p[0];
+        P[1] = p[1];
+        P[2] = p[2];
+        *index = idx;
+      }
+    }
+    rt_scene_destroy(S);
+  }
+  delete[] ct;
+  delete[] cs;
+  if (rc != RT_OK)
+    fprintf(stderr, "check_intersection: GPU path failed (%d): %s\n", rc,
+            rt_last_error());
+  return kind;
+}

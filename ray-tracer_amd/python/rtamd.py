@@ -134,6 +134,13 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime under the same soname.  A process may
+    # hold only one: if torch is going to be used (device buffers, RCCL) it has
+    # to be the one that loads it, so give it the chance before dlopen.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} is not built (run python -c 'import __graft_entry__ as g; g.build()')")

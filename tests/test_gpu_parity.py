@@ -1,0 +1,220 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+golden outputs of the real reference.  Needs an MI355X.
+
+Bar (depth 1, the reference's behaviour):
+  hit-id buffer        bit-exact
+  framebuffer          the task allows +-1 LSB on >= 99.9 % of pixels; the
+                       tests demand bit-exact and only fall back to that
+                       allowance with an explicit, printed mismatch count
+  check_intersection   kind/index/P bit-exact
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_scenes
+import rtamd
+
+pytestmark = pytest.mark.gpu
+
+W, H = 2560, 1440  # the reference's compiled-in frame (renderer.hpp:10-11)
+
+
+def row_crc(a):
+    a = np.ascontiguousarray(a)
+    return np.array([zlib.crc32(a[i].tobytes()) for i in range(a.shape[0])], np.uint32)
+
+
+def assert_frame_parity(fb, ids, fb_ref, ids_ref, what):
+    assert np.array_equal(ids, ids_ref), f"{what}: hit ids differ at " \
+        f"{int((ids != ids_ref).sum())} pixels"
+    if np.array_equal(fb, fb_ref):
+        return
+    diff = np.abs(fb.astype(np.int16) - fb_ref.astype(np.int16)).max(-1)
+    n_bad = int((diff > 1).sum())
+    n_any = int((diff > 0).sum())
+    print(f"{what}: {n_any} pixels differ, {n_bad} by more than 1 LSB")
+    assert n_bad <= 0.001 * diff.size, f"{what}: {n_bad} pixels off by > 1 LSB"
+    pytest.fail(f"{what}: framebuffer not bit-exact ({n_any} pixels differ by 1 LSB)")
+
+
+@pytest.mark.parametrize("name", ["shipped", "mixed", "g30"])
+def test_reference_frame_golden(golden, name):
+    """2560x1440 frames against digests of the real reference's output."""
+    sc = golden_scenes.full_frame_scenes()[name]
+    fb, ids, n_rays = rtamd.render(sc, W, H)
+    assert np.array_equal(row_crc(ids), golden[f"{name}_idcrc"])
+    assert np.array_equal(row_crc(fb), golden[f"{name}_fbcrc"])
+    px = golden[f"{name}_px"]
+    assert np.array_equal(fb[px[:, 0], px[:, 1]], golden[f"{name}_pxfb"])
+    assert np.array_equal(ids[px[:, 0], px[:, 1]], golden[f"{name}_pxid"])
+    assert n_rays == W * H + int((ids >= 0).sum()) * sc.l_size
+
+
+def test_reference_frame_live(ref):
+    """The same comparison against the real reference run on this host."""
+    sc = golden_scenes.mixed_scene(seed=31, n_spheres=80, n_tris=16, n_lights=2)
+    fb, ids, _ = rtamd.render(sc, ref.W, ref.H)
+    assert_frame_parity(fb, ids, ref.render(sc), ref.hit_ids(sc), "live reference")
+
+
+@pytest.mark.parametrize("w,h", [(333, 217), (64, 64), (1920, 1080), (7, 5)])
+def test_other_sizes_vs_oracle(oracle, w, h):
+    sc = golden_scenes.mixed_scene(seed=4)
+    fb, ids, n = rtamd.render(sc, w, h)
+    fo, io, no = oracle.render(sc, w, h)
+    assert_frame_parity(fb, ids, fo, io, f"{w}x{h}")
+    assert n == no
+
+
+def test_camera_variants_vs_oracle(oracle):
+    sc = golden_scenes.mixed_scene(seed=6)
+    for fov, origin, pz in [(60, (0, 0, 1), -1.0), (90, (1.5, -0.5, 3.0), -1.0),
+                            (120, (0, 2, 0), -2.0)]:
+        cam = rtamd.default_camera(fov)
+        cam.origin[0], cam.origin[1], cam.origin[2] = origin
+        cam.plane_z = pz
+        fb, ids, n = rtamd.render(sc, 640, 360, cam=cam)
+        fo, io, no = oracle.render(sc, 640, 360, cam=cam)
+        assert_frame_parity(fb, ids, fo, io, f"fov {fov} eye {origin}")
+        assert n == no
+
+
+def test_1k_grid_1080p_vs_oracle(oracle):
+    """The 1k-sphere configuration (32x32 grid, 1920x1080) at depth 1."""
+    sc = rtamd.grid_scene(32, 32)
+    fb, ids, n = rtamd.render(sc, 1920, 1080)
+    fo, io, no = oracle.render(sc, 1920, 1080)
+    assert_frame_parity(fb, ids, fo, io, "1k grid")
+    assert n == no
+
+
+def test_empty_and_degenerate_scenes(oracle):
+    e = np.zeros((0, 3), np.float32)
+    empty = rtamd.Scene(np.zeros((0, 9)), np.zeros((0, 3)), e, np.zeros(0), np.zeros((0, 3)), e)
+    fb, ids, n = rtamd.render(empty, 40, 24)
+    assert (fb[..., :3] == 0).all() and (fb[..., 3] == 255).all() and (ids == -1).all()
+    assert n == 40 * 24
+    # no lights: hits are found but nothing is added (renderer.cpp:82 loop is empty)
+    sc = golden_scenes.mixed_scene(seed=8)
+    nolight = rtamd.Scene(sc.tris, sc.color_tri, sc.spheres, sc.radius, sc.color_sphere, e)
+    fb, ids, n = rtamd.render(nolight, 200, 120)
+    fo, io, no = oracle.render(nolight, 200, 120)
+    assert_frame_parity(fb, ids, fo, io, "no lights")
+    assert (fb[..., :3] == 0).all() and n == no == 200 * 120
+    # spheres only / triangles only
+    for keep_t, keep_s in [(0, 1), (1, 0)]:
+        s2 = rtamd.Scene(sc.tris[:sc.t_size * keep_t], sc.color_tri[:sc.t_size * keep_t],
+                         sc.spheres[:sc.s_size * keep_s], sc.radius[:sc.s_size * keep_s],
+                         sc.color_sphere[:sc.s_size * keep_s], sc.lights)
+        fb, ids, n = rtamd.render(s2, 320, 200)
+        fo, io, no = oracle.render(s2, 320, 200)
+        assert_frame_parity(fb, ids, fo, io, f"tris={keep_t} spheres={keep_s}")
+        assert n == no
+
+
+def test_check_intersection_bulk(oracle, golden):
+    sc = golden_scenes.mixed_scene()
+    o, d = golden_scenes.random_rays(20000, seed=11)
+    with rtamd.DeviceScene(sc) as ds:
+        kind, index, P = ds.check_intersection(o, d)
+    assert np.array_equal(kind, golden["rays_kind"].astype(np.int32))
+    assert np.array_equal(index, golden["rays_index"].astype(np.int32))
+    m = kind != 0
+    assert np.array_equal(P.view(np.uint32)[m], golden["rays_P"][m])
+    # a second seed, against the oracle
+    sc2 = golden_scenes.mixed_scene(seed=41, n_spheres=333, n_tris=9)
+    o, d = golden_scenes.random_rays(50001, seed=42)
+    with rtamd.DeviceScene(sc2) as ds:
+        k1, i1, p1 = ds.check_intersection(o, d)
+    k0, i0, p0 = oracle.check_intersection(sc2, o, d)
+    assert np.array_equal(k0, k1) and np.array_equal(i0, i1)
+    m = k0 != 0
+    assert np.array_equal(p0.view(np.uint32)[m], p1.view(np.uint32)[m])
+
+
+def test_sphere_edge_cases_through_check_intersection(oracle):
+    """Each known-answer sphere case as a one-sphere scene: tangent rays
+    (discr == 0), origin inside / on the surface, b in (0, 0.001], zero radius,
+    zero direction (maths.cpp:132-152)."""
+    k = golden_scenes.kat_inputs()
+    n = 64
+    for i in range(n):
+        sc = rtamd.Scene(np.zeros((0, 9)), np.zeros((0, 3)), k["sph_centre"][i:i + 1],
+                         k["sph_radius"][i:i + 1], np.array([[1, 2, 3]]), np.zeros((0, 3)))
+        with rtamd.DeviceScene(sc) as ds:
+            k1, i1, p1 = ds.check_intersection(k["sph_orig"][i:i + 1], k["sph_dir"][i:i + 1])
+        k0, i0, p0 = oracle.check_intersection(sc, k["sph_orig"][i:i + 1], k["sph_dir"][i:i + 1])
+        assert k0[0] == k1[0] and i0[0] == i1[0], f"case {i}"
+        if k0[0]:
+            assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)), f"case {i}"
+
+
+def test_band_sharding_matches_whole_frame():
+    """Bands dealt round-robin to 3 callers tile the frame exactly."""
+    import torch
+    sc = golden_scenes.mixed_scene(seed=9)
+    w, h = 500, 300
+    whole, ids_whole, n_whole = rtamd.render(sc, w, h)
+    fb = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    ids = torch.full((h, w), -7, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    with rtamd.DeviceScene(sc) as ds:
+        for r in range(3):
+            ds.render_device(fb.data_ptr(), ids.data_ptr(), w, h, band_rows=16, band_index=r,
+                             band_count=3, stream=torch.cuda.current_stream().cuda_stream,
+                             dev_ray_count=cnt.data_ptr())
+        torch.cuda.synchronize()
+    assert np.array_equal(fb.cpu().numpy(), whole)
+    assert np.array_equal(ids.cpu().numpy(), ids_whole)
+    assert int(cnt.item()) == n_whole
+
+
+def test_bad_arguments_fail_loudly():
+    sc = golden_scenes.mixed_scene()
+    with pytest.raises(rtamd.RtError):
+        rtamd.render(sc, 0, 10)
+    with pytest.raises(rtamd.RtError):
+        rtamd.render(sc, 16, 16, max_depth=0)
+    d = sc.desc()
+    d.s_size = -1
+    import ctypes as C
+    cam = rtamd.default_camera()
+    buf = np.zeros((4, 4, 4), np.uint8)
+    assert rtamd.lib().gpu_render(C.byref(d), C.byref(cam), buf.ctypes.data, 4, 4, 1) == \
+        rtamd.RT_ERR_BAD_ARG
+    assert b"negative" in rtamd.lib().rt_last_error()
+
+
+def test_reference_signature_shim(golden, oracle):
+    """librt_shim.so exports render()/check_intersection() with the reference's
+    own C++ signatures (renderer.hpp:16-23); a host program built against the
+    reference's header links to it unchanged."""
+    import ctypes as C
+    import os
+    shim = C.CDLL(os.path.join(rtamd.PKG_DIR, "host", "librt_shim.so"))
+    render = getattr(shim, "_Z6renderPhiPfS_iS0_S0_S_iS0_i")
+    check = getattr(shim, "_Z18check_intersectionPfiS_S_iS_PiS_S_")
+    sc = golden_scenes.full_frame_scenes()["shipped"]
+    fb = np.zeros((H, W, 4), np.uint8)
+    vp = C.c_void_p
+    render.restype = None
+    render(vp(fb.ctypes.data), 90, vp(sc.tris.ctypes.data), vp(sc.color_tri.ctypes.data),
+           sc.t_size, vp(sc.spheres.ctypes.data), vp(sc.radius.ctypes.data),
+           vp(sc.color_sphere.ctypes.data), sc.s_size, vp(sc.lights.ctypes.data), sc.l_size)
+    assert np.array_equal(row_crc(fb), golden["shipped_fbcrc"])
+
+    o, d = oracle.primary_rays(W, H, [(700, 1280), (3, 3), (720, 1300)])
+    k0, i0, p0 = oracle.check_intersection(sc, o, d)
+    for r in range(len(o)):
+        P = np.zeros(3, np.float32)
+        idx = C.c_int(-5)
+        k = check(vp(sc.tris.ctypes.data), sc.t_size, vp(sc.spheres.ctypes.data),
+                  vp(sc.radius.ctypes.data), sc.s_size, vp(P.ctypes.data), C.byref(idx),
+                  vp(o[r].ctypes.data), vp(d[r].ctypes.data))
+        assert k == k0[r]
+        if k:
+            assert idx.value == i0[r] and np.array_equal(P.view(np.uint32), p0[r].view(np.uint32))
+        else:
+            assert idx.value == -5  # untouched on a miss
