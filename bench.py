@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--screen", choices=["on", "off"], default="on",
+                    help="beam screen (default) or the plain every-ray-every-sphere loop")
     args = ap.parse_args()
 
     import torch
@@ -107,6 +109,7 @@ def main():
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     ds = rtamd.DeviceScene(sc)
+    rtamd.set_screen(args.screen == "on")
     fb_bands = fb.view(n_bands, band_rows * w * 4)
     gather_list = None
     if world > 1 and rank == 0:
@@ -185,8 +188,26 @@ def main():
                          "flop_per_ray": n_tests_per_ray,
                          "note": "algorithmic FLOP = rays x (25 x spheres + 107 x triangles); "
                                  "parity forbids FMA, so 1 flop/lane/instr caps executed "
-                                 "arithmetic at 1/2 of peak"},
+                                 "arithmetic at 1/2 of peak; with the beam screen on most "
+                                 "of that arithmetic is proven unnecessary and skipped, so "
+                                 "frac can exceed 1 (plain_loop = screen off)"},
         }
+        out["config"]["screen"] = args.screen
+        if world == 1 and args.screen == "on":
+            # the same frame with the screen off: the brute-force formulation the
+            # FP32 roofline is defined on (every ray against every primitive)
+            rtamd.set_screen(False)
+            step(False)
+            torch.cuda.synchronize()
+            kernel_ms.clear()
+            for _ in range(2):
+                step(True)
+            rtamd.set_screen(True)
+            bf_ms = float(np.mean(kernel_ms))
+            bf = my_rays_per_launch * n_tests_per_ray / (bf_ms * 1e-3) / 1e12
+            out["roofline"]["plain_loop"] = {
+                "kernel_ms": bf_ms, "achieved": bf, "frac": bf / PEAK_FP32_VALU_TFLOPS,
+                "mrays_per_s": my_rays_per_launch / (bf_ms * 1e-3) / 1e6}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, w, h, depth)
         print(json.dumps(out))

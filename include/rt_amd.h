@@ -132,6 +132,25 @@ typedef struct rt_frame {
 int rt_render_device(rt_scene *scene, const camera *cam, const rt_frame *frame,
                      uint64_t *dev_ray_count);
 
+/* ---- the beam screen (no counterpart in the reference) ---------------------
+ * By default each wave first screens the spheres, 64 at a time, against a cone
+ * that contains all of its rays, and runs the reference's per-ray arithmetic
+ * only on spheres the cone can touch.  The screen is conservative by
+ * construction, so images, ids and ray counts are identical with it on or off;
+ * it only removes work.  rt_set_screen(0) selects the plain loop that tests
+ * every ray against every sphere (used to measure the brute-force roofline).
+ * Process-wide; not thread-safe against concurrent renders.                   */
+void rt_set_screen(int enabled);
+int rt_get_screen(void);
+
+/* As rt_render_device, with a slow self-checking build of the kernel that
+ * re-tests every sphere the screen dropped.  dev_stats (device, 2 x uint64,
+ * zeroed by the caller) receives {wave-level drops for which some ray's
+ * discriminant test (maths.cpp:132-133) passes - must be 0, spheres kept}.    */
+int rt_render_device_selfcheck(rt_scene *scene, const camera *cam,
+                               const rt_frame *frame, uint64_t *dev_ray_count,
+                               uint64_t *dev_stats);
+
 /* Bulk form of check_intersection (renderer.hpp:21-23): n rays, host arrays.
  * orig/dir are 3*n floats; kind (0 none / 1 triangle / 2 sphere), index
  * (class-local, untouched semantics -> -1 on miss) are n int32; P is 3*n

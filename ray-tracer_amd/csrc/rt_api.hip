@@ -21,6 +21,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+int g_screen = 1; // rt_set_screen
 
 int fail(int code, const char *fmt, ...) {
   va_list ap;
@@ -261,8 +262,8 @@ int rt_scene_create(const scene_desc *scene, rt_scene **out) {
 
 void rt_scene_destroy(rt_scene *scene) { delete scene; }
 
-int rt_render_device(rt_scene *S, const camera *cam, const rt_frame *fr,
-                     uint64_t *dev_ray_count) {
+static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr,
+                              uint64_t *dev_ray_count, uint64_t *dev_verify) {
   if (!S || !cam || !fr)
     return fail(RT_ERR_BAD_ARG, "scene, camera or frame is NULL");
   if (!fr->dev_fb)
@@ -302,9 +303,25 @@ int rt_render_device(rt_scene *S, const camera *cam, const rt_frame *fr,
                   ? (bands_total - fr->band_index + band_count - 1) / band_count
                   : 0;
   HIP_TRY(rt::launch_render(S->dev(), camera_dev(cam, fr->w, fr->h), f,
-                            owned * (band_rows / 8), st));
+                            owned * (band_rows / 8), g_screen != 0,
+                            (unsigned long long *)dev_verify, st));
   return RT_OK;
 }
+
+int rt_render_device(rt_scene *S, const camera *cam, const rt_frame *fr,
+                     uint64_t *dev_ray_count) {
+  return render_device_impl(S, cam, fr, dev_ray_count, nullptr);
+}
+
+int rt_render_device_selfcheck(rt_scene *S, const camera *cam, const rt_frame *fr,
+                               uint64_t *dev_ray_count, uint64_t *dev_stats) {
+  if (!dev_stats)
+    return fail(RT_ERR_BAD_ARG, "dev_stats is NULL");
+  return render_device_impl(S, cam, fr, dev_ray_count, dev_stats);
+}
+
+void rt_set_screen(int enabled) { g_screen = enabled; }
+int rt_get_screen(void) { return g_screen; }
 
 int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
                    int32_t *hit_ids, uint64_t *n_rays, int w, int h,

@@ -180,16 +180,134 @@ __device__ __forceinline__ bool triangle_test(const TriRec &T, float no,
   return true;
 }
 
+// ---- ray / sphere, the whole of maths.cpp:121-161 ------------------------------
+// (cx,cy,cz,rr) is the sphere record; a = dir.dir and a4 = 4*a are per ray.
+__device__ __forceinline__ bool sphere_exact(float cx, float cy, float cz,
+                                             float rr, float a, float a4,
+                                             float ox, float oy, float oz,
+                                             float dx, float dy, float dz,
+                                             float &Px, float &Py, float &Pz) {
+  float Lx = ox - cx, Ly = oy - cy, Lz = oz - cz;  // maths.cpp:126
+  float b = 2.0f * dot3(dx, dy, dz, Lx, Ly, Lz);   // maths.cpp:128
+  float c = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - rr;     // maths.cpp:129
+  float bb = b * b, ac = a4 * c;                   // maths.cpp:132
+  if (bb < ac)                                     // discr < 0, maths.cpp:133
+    return false;
+  return sphere_finish(a, b, c, bb, ac, ox, oy, oz, dx, dy, dz, Px, Py, Pz);
+}
+
+// ---- wave-level helpers ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---- the beam screen ---------------------------------------------------------------
+// The rays of one wave are coherent: the 64 primary rays of an 8x8 tile leave the
+// eye inside a cone a few milliradians wide, and the 64 shadow rays towards one
+// light all pass (to rounding) through the light.  Before the per-ray tests each
+// wave therefore SCREENS the spheres 64 at a time, one sphere per lane, against a
+// cone that contains all its rays' lines; only spheres the cone can touch are
+// broadcast to the whole wave for the reference's per-ray arithmetic, in index
+// order, so results (including ties) are the same as testing every sphere.
+//
+// The screen must never drop a sphere whose discriminant test
+// (maths.cpp:132-133, evaluated in float) could pass for some ray.  Bound used:
+// with L = o - c and |d|^2 = a, the float test passing implies
+//     dist(c, line)^2  <=  r^2 + 21 u (|L|^2 + r^2),     u = 2^-24
+// (3-term dot products contribute <= 3u relative to |d||L|, the remaining
+// products/sums u each).  The screen uses eps = 2^-16 = 64u in place of 21u and,
+// for rays that only approximately pass through the apex X (shadow rays:
+// d = normalize(X - P) in float, angular error < 4u), widens the radius by
+// delta = 2^-20 * max|X - P|.  Its own float arithmetic is made one-sided:
+//   - sin(alpha) is inflated (x(1+2^-8) + 2^-30 on the square, x(1+2^-18) +
+//     2^-20 on the root), cos(alpha) deflated by (1-2^-18);
+//   - |M|^2 is deflated by (1-2^-19) before p^2 is taken from it;
+//   - every comparison is written so that NaN/inf means "keep".
+// Rays whose a = d.d is 0 or NaN can never produce an accepted hit in the
+// reference (t becomes inf/NaN, |P| is then not below +inf) and are left out.
+struct Beam {
+  float Xx, Xy, Xz; // apex
+  float Ux, Uy, Uz; // unit axis
+  float sin_a, cos_a;
+  float K;     // 2 eps D^2 + absolute slack, D = max distance ray origin - apex
+  float delta; // radius widening for lines that miss the apex by rounding
+  bool narrow; // false: do not screen, test everything
+};
+
+#define RT_SCREEN_EPS 1.52587890625e-05f /* 2^-16 */
+
+__device__ __forceinline__ Beam make_beam(bool lv, float a, float dx, float dy,
+                                          float dz, float Xx, float Xy, float Xz,
+                                          float Dk) {
+  Beam B;
+  B.Xx = Xx;
+  B.Xy = Xy;
+  B.Xz = Xz;
+  const bool sane = a > 9.094947e-13f && a < 1.0995116e12f; // 2^-40 .. 2^40
+  float sx = wave_sum(lv ? dx : 0.f), sy = wave_sum(lv ? dy : 0.f),
+        sz = wave_sum(lv ? dz : 0.f);
+  float n2 = fmaf(sz, sz, fmaf(sy, sy, sx * sx));
+  float inv = 1.0f / sqrtf(n2);
+  float Ux = uniform(sx * inv), Uy = uniform(sy * inv), Uz = uniform(sz * inv);
+  float cx = Uy * dz - Uz * dy, cy = Uz * dx - Ux * dz, cz = Ux * dy - Uy * dx;
+  float s2k = fmaf(cz, cz, fmaf(cy, cy, cx * cx)) / a;
+  float along = fmaf(Uz, dz, fmaf(Uy, dy, Ux * dx));
+  bool bad = lv && !(sane && along > 0.f && s2k >= 0.f);
+  float s2 = uniform(wave_max(lv ? s2k : 0.f));
+  s2 = fmaf(s2, 1.00390625f, 9.313225746154785e-10f); // (1+2^-8), 2^-30
+  float D = uniform(wave_max(lv ? Dk : 0.f));
+  B.Ux = Ux;
+  B.Uy = Uy;
+  B.Uz = Uz;
+  B.sin_a = fmaf(sqrtf(s2), 1.000003814697265625f, 9.5367431640625e-07f);
+  B.cos_a = sqrtf(1.0f - s2) * 0.999996185302734375f;
+  B.K = fmaf(2.0f * RT_SCREEN_EPS * D, D, 8.271806125530277e-25f); // + 2^-80
+  B.delta = D * 9.5367431640625e-07f;                               // 2^-20
+  B.narrow = !__any(bad) && s2 < 0.25f && n2 > 0.f && D < 1.8446744e19f;
+  return B;
+}
+
+// true = the sphere may be hit by some ray of the beam (or nothing can be proved)
+__device__ __forceinline__ bool beam_keeps(const Beam &B, float4 g) {
+  float Mx = g.x - B.Xx, My = g.y - B.Xy, Mz = g.z - B.Xz;
+  float m2 = fmaf(Mz, Mz, fmaf(My, My, Mx * Mx));
+  float p = fmaf(B.Uz, Mz, fmaf(B.Uy, My, B.Ux * Mx));
+  float q2 = fmaf(-p, p, m2 * 0.99999809265136719f); // (1-2^-19)
+  float q = __builtin_amdgcn_sqrtf(fmaxf(q2, 0.f));
+  float lhs = fmaf(q, B.cos_a, -(fabsf(p) * B.sin_a)); // <= |M| sin(theta-alpha)
+  float reff2 = fmaf(g.w, 1.0f + RT_SCREEN_EPS, fmaf(m2, 2.0f * RT_SCREEN_EPS, B.K));
+  float reff = fmaf(__builtin_amdgcn_sqrtf(reff2), 1.00000095367431640625f, B.delta);
+  return !(lhs > reff);
+}
+
 // ---- check_intersection (renderer.cpp:145-193) ---------------------------------
 // One lane = one ray; the primitive being tested is the same for every lane of
-// the wave, so its record is read through wave-uniform (scalar) loads and the
-// per-lane work is the reference's arithmetic only.
+// the wave, so its record is read through wave-uniform (scalar) loads or a lane
+// broadcast and the per-lane work is the reference's arithmetic only.
 //
 // FROM_EYE: the ray starts at the camera eye, so L, c (spheres) and N.orig
 //           (triangles) come precomputed from the scene records.
 // ANY_HIT : only "is anything hit" is wanted (shadow rays, renderer.cpp:119);
 //           the loop may stop as soon as every live lane has a hit, which
 //           cannot change the answer.
+// BEAM    : the wave's rays share the apex (Xx,Xy,Xz) (the eye, or the light a
+//           shadow ray aims at) and are screened as described above; Dk is the
+//           lane's distance from its ray origin to the apex.
 //
 // Nearest is by |P| from the WORLD origin with strict '>' (lowest index wins in
 // a class); between classes a triangle wins ties ('<=', renderer.cpp:181).  A
@@ -201,10 +319,17 @@ struct Hit {
   float Px, Py, Pz;
 };
 
-template <bool FROM_EYE, bool ANY_HIT>
+struct ScreenStats { // filled only by the verification build of the kernels
+  unsigned long long *dropped_but_candidate;
+  unsigned long long *kept;
+};
+
+template <bool FROM_EYE, bool ANY_HIT, bool BEAM, bool VERIFY = false>
 __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                                      float oy, float oz, float dx, float dy,
-                                     float dz) {
+                                     float dz, float Xx = 0.f, float Xy = 0.f,
+                                     float Xz = 0.f, float Dk = 0.f,
+                                     ScreenStats st = ScreenStats{nullptr, nullptr}) {
   float len_t = RT_INF, len_s = RT_INF;
   int idx_t = -1, idx_s = -1;
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
@@ -232,12 +357,77 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   // ---- spheres, renderer.cpp:168-177 ----
   const float a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
   const float a4 = 4.0f * a;                    // maths.cpp:132, (4*a)*c
-  const float4 *__restrict__ rec = FROM_EYE ? sc.sph_prim : sc.sph_geo;
   bool seek = live && !(ANY_HIT && idx_t >= 0);
-  if (!ANY_HIT || __any(seek)) {
+
+  bool screened = false;
+  if (BEAM) {
+    // rays with a == 0 or NaN never yield an accepted sphere hit (see above)
+    const bool lv = seek && (a > 0.f);
+    if (__any(lv)) {
+      const Beam B = make_beam(lv, a, dx, dy, dz, Xx, Xy, Xz, Dk);
+      if (B.narrow) {
+        screened = true;
+        const int lane = threadIdx.x & 63;
+        bool want = lv;
+        for (int base = 0; base < sc.s_size; base += 64) {
+          const int j = base + lane;
+          const float4 g = sc.sph_geo[j < sc.s_size ? j : sc.s_size - 1];
+          const bool keep = (j < sc.s_size) && beam_keeps(B, g);
+          unsigned long long mask = __ballot(keep);
+          if (VERIFY) {
+            // count spheres the screen dropped although some ray's discriminant
+            // test passes: must stay zero
+            unsigned long long dropped = __ballot((j < sc.s_size) && !keep);
+            while (dropped) {
+              const int k = __builtin_ctzll(dropped);
+              dropped &= dropped - 1;
+              float cx = lane_value(g.x, k), cy = lane_value(g.y, k),
+                    cz = lane_value(g.z, k), rr = lane_value(g.w, k);
+              float Lx = ox - cx, Ly = oy - cy, Lz = oz - cz;
+              float b = 2.0f * dot3(dx, dy, dz, Lx, Ly, Lz);
+              float c = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - rr;
+              bool cand = lv && !(b * b < a4 * c);
+              unsigned long long viol = __ballot(cand);
+              if (viol && lane == 0)
+                atomicAdd(st.dropped_but_candidate, 1ull);
+            }
+            if (lane == 0)
+              atomicAdd(st.kept, (unsigned long long)__builtin_popcountll(mask));
+          }
+          while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            float cx = lane_value(g.x, k), cy = lane_value(g.y, k),
+                  cz = lane_value(g.z, k), rr = lane_value(g.w, k);
+            float Px, Py, Pz;
+            if (want && sphere_exact(cx, cy, cz, rr, a, a4, ox, oy, oz, dx, dy,
+                                     dz, Px, Py, Pz)) {
+              float len = length3(Px, Py, Pz);
+              if (len_s > len) { // renderer.cpp:170, strict
+                len_s = len;
+                idx_s = base + k;
+                sPx = Px;
+                sPy = Py;
+                sPz = Pz;
+                if (ANY_HIT)
+                  want = false;
+              }
+            }
+          }
+          if (ANY_HIT && !__any(want))
+            break;
+        }
+      }
+    } else {
+      screened = true; // no lane can get a sphere hit
+    }
+  }
+
+  if (!screened && (!ANY_HIT || __any(seek))) {
+    const float4 *__restrict__ rec = FROM_EYE ? sc.sph_prim : sc.sph_geo;
     for (int i = 0; i < sc.s_pad; i += SPH_UNROLL) {
       float b[SPH_UNROLL], c[SPH_UNROLL], bb[SPH_UNROLL], ac[SPH_UNROLL];
-      bool any_cand = false;
+      unsigned long long cand = 0;
 #pragma unroll
       for (int u = 0; u < SPH_UNROLL; u++) {
         const float4 s = rec[i + u];
@@ -258,9 +448,9 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
         ac[u] = a4 * c[u];
         // maths.cpp:132-133: discr = bb - ac is negative exactly when bb < ac
         // (a float difference has the sign of the exact difference).
-        any_cand |= !(bb[u] < ac[u]);
+        cand |= __ballot(!(bb[u] < ac[u]));
       }
-      if (any_cand) {
+      if (cand) {
 #pragma unroll
         for (int u = 0; u < SPH_UNROLL; u++) {
           if (seek && !(bb[u] < ac[u]) && (i + u) < sc.s_size) {

@@ -48,8 +48,13 @@ struct CheckArgs {
 
 hipError_t launch_prep_scene(const PrepArgs &a, hipStream_t st);
 hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st);
+// beam: screen spheres per wave before the per-ray tests (same results, far
+// less work).  verify_stats: device uint64[2] {spheres dropped although a ray's
+// discriminant test passes (must stay 0), spheres kept}; selects a slow
+// self-checking build of the kernel.
 hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
-                         const FrameDev &f, int owned_tile_rows, hipStream_t st);
+                         const FrameDev &f, int owned_tile_rows, bool beam,
+                         unsigned long long *verify_stats, hipStream_t st);
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);
 
 } // namespace rt

@@ -164,8 +164,9 @@ __device__ __forceinline__ float phong_light(const Surface &s, const Hit &h,
 // block's pixel writes cover 128 contiguous bytes per row.  blockIdx.y counts
 // the tile rows this call owns; bands of band_rows rows are dealt round-robin
 // over band_count callers (row sharding, renderer.cpp:27-28).
+template <bool BEAM, bool VERIFY>
 __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
-                                                FrameDev f) {
+                                                FrameDev f, ScreenStats st) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int tiles_per_band = f.band_rows >> 3;
@@ -183,7 +184,9 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
   float dx = px - cam.ox, dy = py - cam.oy, dz = cam.plane_z - cam.oz;
   normalize3(dx, dy, dz);
 
-  Hit h = trace<true, false>(sc, inside, cam.ox, cam.oy, cam.oz, dx, dy, dz);
+  Hit h = trace<true, false, BEAM, VERIFY>(sc, inside, cam.ox, cam.oy, cam.oz,
+                                           dx, dy, dz, cam.ox, cam.oy, cam.oz,
+                                           0.f, st);
 
   uint32_t fb0 = 0, fb1 = 0, fb2 = 0; // renderer.cpp:50-52
   uint32_t n_rays = inside ? 1u : 0u;
@@ -195,11 +198,17 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
       s = surface_at(sc, h);
     for (int l = 0; l < sc.l_size; l++) { // renderer.cpp:82
       float fColor[3] = {0, 0, 0};
-      float lx = 0, ly = 0, lz = 0, angle = 0;
-      if (hit)
-        angle = phong_light(s, h, dx, dy, dz, sc.lights[l], fColor, lx, ly, lz);
-      // renderer.cpp:119: shadow ray from exactly P, no distance limit
-      Hit sh = trace<false, true>(sc, hit, h.Px, h.Py, h.Pz, lx, ly, lz);
+      float lx = 0, ly = 0, lz = 0, angle = 0, dist = 0;
+      const float4 light = sc.lights[l];
+      if (hit) {
+        angle = phong_light(s, h, dx, dy, dz, light, fColor, lx, ly, lz);
+        dist = length3(light.x - h.Px, light.y - h.Py, light.z - h.Pz);
+      }
+      // renderer.cpp:119: shadow ray from exactly P, no distance limit.  All
+      // shadow rays of the wave aim at the light: that is the beam's apex.
+      Hit sh = trace<false, true, BEAM, VERIFY>(sc, hit, h.Px, h.Py, h.Pz, lx, ly,
+                                                lz, light.x, light.y, light.z,
+                                                dist, st);
       if (hit) {
         n_rays++;
         if (sh.kind == 0) {
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256) void k_check(SceneDev sc, CheckArgs a) {
   long rr = live ? r : 0;
   float ox = a.orig[3 * rr], oy = a.orig[3 * rr + 1], oz = a.orig[3 * rr + 2];
   float dx = a.dir[3 * rr], dy = a.dir[3 * rr + 1], dz = a.dir[3 * rr + 2];
-  Hit h = trace<false, false>(sc, live, ox, oy, oz, dx, dy, dz);
+  Hit h = trace<false, false, false>(sc, live, ox, oy, oz, dx, dy, dz);
   if (live) {
     a.kind[r] = h.kind;
     a.index[r] = h.index;
@@ -274,12 +283,21 @@ hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
-                         const FrameDev &f, int owned_tile_rows,
-                         hipStream_t st) {
+                         const FrameDev &f, int owned_tile_rows, bool beam,
+                         unsigned long long *verify_stats, hipStream_t st) {
   if (owned_tile_rows <= 0)
     return hipSuccess;
   dim3 grid((f.w + 31) / 32, owned_tile_rows);
-  hipLaunchKernelGGL(k_render, grid, dim3(256), 0, st, sc, cam, f);
+  ScreenStats ss{nullptr, nullptr};
+  if (verify_stats) {
+    ss.dropped_but_candidate = verify_stats;
+    ss.kept = verify_stats + 1;
+    hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, st, sc, cam, f, ss);
+  } else if (beam) {
+    hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, st, sc, cam, f, ss);
+  } else {
+    hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, st, sc, cam, f, ss);
+  }
   return hipGetLastError();
 }
 

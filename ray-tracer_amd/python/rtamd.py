@@ -159,6 +159,10 @@ def lib() -> C.CDLL:
     L.rt_scene_destroy.restype = None
     L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame),
                                    C.c_void_p]
+    L.rt_render_device_selfcheck.argtypes = [C.c_void_p, C.POINTER(Camera),
+                                             C.POINTER(Frame), C.c_void_p, C.c_void_p]
+    L.rt_set_screen.argtypes = [C.c_int]
+    L.rt_set_screen.restype = None
     L.gpu_check_intersection.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
@@ -168,6 +172,11 @@ def lib() -> C.CDLL:
 def _check(code: int):
     if code != RT_OK:
         raise RtError(code, lib().rt_last_error().decode())
+
+
+def set_screen(enabled: bool):
+    """rt_set_screen: beam screen on (default) or the plain every-ray-every-sphere loop."""
+    lib().rt_set_screen(1 if enabled else 0)
 
 
 def render(scene: Scene, w: int, h: int, max_depth: int = 1,
@@ -223,12 +232,17 @@ class DeviceScene:
     def render_device(self, dev_fb: int, dev_ids: Optional[int], w: int, h: int,
                       max_depth: int = 1, cam: Optional[Camera] = None,
                       band_rows: int = 8, band_index: int = 0, band_count: int = 1,
-                      stream: Optional[int] = None, dev_ray_count: Optional[int] = None):
+                      stream: Optional[int] = None, dev_ray_count: Optional[int] = None,
+                      dev_selfcheck_stats: Optional[int] = None):
         cam = cam or default_camera()
         f = Frame(dev_fb, dev_ids, w, h, max_depth, band_rows, band_index, band_count,
                   stream)
-        _check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(f),
-                                      dev_ray_count))
+        if dev_selfcheck_stats is not None:
+            _check(lib().rt_render_device_selfcheck(self.handle, C.byref(cam), C.byref(f),
+                                                    dev_ray_count, dev_selfcheck_stats))
+        else:
+            _check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(f),
+                                          dev_ray_count))
 
     def check_intersection(self, orig: np.ndarray, dir: np.ndarray):
         orig = np.ascontiguousarray(orig, np.float32).reshape(-1, 3)

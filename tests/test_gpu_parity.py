@@ -218,3 +218,46 @@ def test_reference_signature_shim(golden, oracle):
             assert idx.value == i0[r] and np.array_equal(P.view(np.uint32), p0[r].view(np.uint32))
         else:
             assert idx.value == -5  # untouched on a miss
+
+
+def test_plain_loop_equals_screened(oracle):
+    """rt_set_screen(0): every ray against every sphere.  Same bytes."""
+    sc = golden_scenes.mixed_scene(seed=12, n_spheres=200)
+    try:
+        rtamd.set_screen(False)
+        fb0, ids0, n0 = rtamd.render(sc, 640, 400)
+    finally:
+        rtamd.set_screen(True)
+    fb1, ids1, n1 = rtamd.render(sc, 640, 400)
+    fo, io, no = oracle.render(sc, 640, 400)
+    assert_frame_parity(fb0, ids0, fo, io, "plain loop")
+    assert_frame_parity(fb1, ids1, fo, io, "screened")
+    assert n0 == n1 == no
+
+
+@pytest.mark.parametrize("name,w,h", [("shipped", 2560, 1440), ("mixed", 1280, 720),
+                                      ("g100", 3840, 2160), ("bigsphere", 800, 600)])
+def test_screen_never_drops_a_candidate(name, w, h):
+    """The self-checking kernel re-tests every sphere the screen dropped with the
+    reference's discriminant arithmetic for all 64 rays of the wave."""
+    import torch
+    if name == "g100":
+        sc = rtamd.grid_scene(100, 100)
+    elif name == "bigsphere":
+        # spheres that are huge relative to their distance, and tiny ones
+        sc = golden_scenes.mixed_scene(seed=13)
+        sc.radius[:6] = [400, 90, 30, 0.01, 0.001, 12]
+        sc.spheres[0] = [0, -405, -30]
+    else:
+        sc = golden_scenes.full_frame_scenes()[name]
+    fb = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    with rtamd.DeviceScene(sc) as ds:
+        ds.render_device(fb.data_ptr(), None, w, h, dev_selfcheck_stats=stats.data_ptr())
+        torch.cuda.synchronize()
+    dropped_but_candidate, kept = [int(x) for x in stats.cpu()]
+    waves = ((w + 31) // 32 * 4) * ((h + 7) // 8)
+    print(f"{name}: kept {kept} sphere tests over {waves} waves "
+          f"({kept / max(1, waves):.1f} per wave, {sc.s_size} spheres)")
+    assert dropped_but_candidate == 0
+    assert kept > 0
