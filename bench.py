@@ -217,7 +217,7 @@ def main():
 
 
 def default_workload():
-    return "10k-spheres-4k-depth1"
+    return "10k-spheres-4k-depth8"
 
 
 if __name__ == "__main__":

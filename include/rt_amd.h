@@ -43,9 +43,11 @@ typedef enum rt_status {
 /*
  * Per-primitive material.  NOT in the reference: there a primitive carries
  * only an 8-bit colour (main.cpp:287-289, 297-299) and every surface is
- * Phong with KS 0.3 / KD 0.7 / exponent 20 (renderer.cpp:3-5).  A scene whose
- * material pointers are NULL, or whose materials are all zero, renders exactly
- * as the reference does at any max_depth.
+ * Phong with KS 0.3 / KD 0.7 / exponent 20 (renderer.cpp:3-5).  Materials are
+ * read only when max_depth > 1; a scene whose material pointers are NULL, or
+ * whose materials are all zero, renders exactly as the reference does at any
+ * max_depth, and max_depth = 1 renders exactly as the reference whatever the
+ * materials are.
  */
 typedef struct rt_material {
   float reflectivity; /* weight of the mirror bounce, 0..1 */
@@ -116,7 +118,7 @@ typedef struct rt_frame {
   uint8_t *dev_fb;      /* device, 4*w*h bytes, whole frame; required */
   int32_t *dev_ids;     /* device, w*h int32, or NULL */
   int32_t w, h;
-  int32_t max_depth;    /* >= 1 */
+  int32_t max_depth;    /* 1..63 */
   /* Row-band sharding (renderer.cpp:27-28 parallelises rows; here bands of
    * band_rows rows are dealt round-robin): this call renders bands b with
    * b % band_count == band_index.  band_count = 1 renders the whole frame.   */
@@ -131,6 +133,11 @@ typedef struct rt_frame {
  * dev_ray_count (device uint64, or NULL) is incremented by the rays traced.  */
 int rt_render_device(rt_scene *scene, const camera *cam, const rt_frame *frame,
                      uint64_t *dev_ray_count);
+
+/* Bounce rays wait in a queue in HBM sized at 4 rays per pixel of the call.  If a
+ * scene spawns more, the excess is dropped and this reports 1 (blocking read;
+ * gpu_render/gpu_render_ids check it themselves and return RT_ERR_CAPACITY).  */
+int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
 
 /* ---- the beam screen (no counterpart in the reference) ---------------------
  * By default each wave first screens the spheres, 64 at a time, against a cone

@@ -288,7 +288,8 @@ static float phong_light(const hit_info *hi, const float dir[3],
 }
 
 /* ---- the bounce extension (NOT in the reference; parity unpinned) ----------
- * A hit on a primitive with material (kr, kt, ior) at path weight w:
+ * Active only when max_depth > 1.  Then a hit on a primitive with material
+ * (kr, kt, ior) at path weight w:
  *   - local Phong light is weighted by wl = w * ((1 - kr) - kt)
  *   - if depth < max_depth and w*kr >= 2^-8: a mirror ray from P along
  *     normalize(reflect(dir, n)) with weight w*kr
@@ -375,7 +376,9 @@ static uint64_t shade_pixel(const scene_desc *sc, const camera *cam, int w,
       continue;
     hit_normal_color(sc, &hi);
 
-    const rt_material *m = hit_material(sc, hi.kind, hi.index);
+    /* max_depth = 1 is the reference: materials play no part at all */
+    const rt_material *m =
+        max_depth > 1 ? hit_material(sc, hi.kind, hi.index) : &zero_mat;
     float kr = m->reflectivity, kt = m->transparency;
     float wl = r.w * ((1.0f - kr) - kt);
 

@@ -69,6 +69,11 @@ struct rt_scene {
   bool has_mat_tri = false, has_mat_sph = false;
   bool eye_valid = false;
   float eye[3] = {0, 0, 0};
+  // bounce machinery, allocated on the first max_depth > 1 render
+  DevBuf<float4> queue[2];
+  DevBuf<uint32_t> counts; // [0..63] per-level queue lengths, [64] overflow flag
+  DevBuf<uint32_t> extra;  // 3 per pixel
+  size_t queue_capacity = 0, extra_pixels = 0;
 
   rt::SceneDev dev() const {
     rt::SceneDev d;
@@ -101,6 +106,17 @@ int check_scene_desc(const scene_desc *s) {
     return fail(RT_ERR_BAD_ARG, "s_size > 0 but spheres/radius/color_sphere is NULL");
   if (s->l_size > 0 && !s->lights)
     return fail(RT_ERR_BAD_ARG, "l_size > 0 but lights is NULL");
+  const rt_material *mats[2] = {s->mat_tri, s->mat_sphere};
+  const int counts[2] = {s->t_size, s->s_size};
+  for (int k = 0; k < 2; k++)
+    for (int i = 0; mats[k] && i < counts[k]; i++) {
+      const rt_material &m = mats[k][i];
+      if (!(m.reflectivity >= 0.f) || !(m.transparency >= 0.f) ||
+          !(m.reflectivity + m.transparency <= 1.0f))
+        return fail(RT_ERR_BAD_ARG,
+                    "material %d of %s: weights must be >= 0 and sum to <= 1", i,
+                    k ? "spheres" : "triangles");
+    }
   return RT_OK;
 }
 
@@ -205,6 +221,39 @@ int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
   return RT_OK;
 }
 
+constexpr int kMaxDepth = 63;       // depth is stored in 6 bits of the ray tag
+constexpr int kBounceBlocks = 2048; // 8 blocks of 256 lanes per CU
+
+int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels) {
+  size_t want = 4 * owned_pixels + 65536;
+  if (want > 0xfffffff0ull)
+    want = 0xfffffff0ull;
+  if (S->queue_capacity < want) {
+    for (int q = 0; q < 2; q++)
+      HIP_TRY(S->queue[q].alloc(2 * want));
+    S->queue_capacity = want;
+  }
+  if (!S->counts.p) {
+    HIP_TRY(S->counts.alloc(65));
+    HIP_TRY(hipMemset(S->counts.p, 0, 65 * sizeof(uint32_t)));
+  }
+  if (S->extra_pixels < frame_pixels) {
+    HIP_TRY(S->extra.alloc(3 * frame_pixels));
+    HIP_TRY(hipMemset(S->extra.p, 0, 3 * frame_pixels * sizeof(uint32_t)));
+    S->extra_pixels = frame_pixels;
+  }
+  return RT_OK;
+}
+
+rt::RayQueue queue_for_level(rt_scene *S, int level) {
+  rt::RayQueue q;
+  q.items = S->queue[level & 1].p;
+  q.count = S->counts.p + level;
+  q.capacity = (uint32_t)S->queue_capacity;
+  q.overflow = S->counts.p + 64;
+  return q;
+}
+
 rt::CameraDev camera_dev(const camera *cam, int w, int h) {
   rt::CameraDev c;
   c.tan_half = tan(cam->fov_deg * 0.5 * M_PI / 180); // renderer.cpp:35
@@ -280,8 +329,8 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
   if (fr->band_index < 0 || fr->band_index >= band_count)
     return fail(RT_ERR_BAD_ARG, "band_index %d outside [0,%d)", fr->band_index,
                 band_count);
-  if (fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph))
-    return fail(RT_ERR_UNSUPPORTED, "material bounces are not built yet");
+  if (fr->max_depth > kMaxDepth)
+    return fail(RT_ERR_BAD_ARG, "max_depth %d > %d", fr->max_depth, kMaxDepth);
   hipStream_t st = (hipStream_t)fr->stream;
   HIP_TRY(hipSetDevice(S->device));
   int rc = scene_set_eye(S, cam, st);
@@ -302,9 +351,33 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
   int owned = bands_total > fr->band_index
                   ? (bands_total - fr->band_index + band_count - 1) / band_count
                   : 0;
-  HIP_TRY(rt::launch_render(S->dev(), camera_dev(cam, fr->w, fr->h), f,
-                            owned * (band_rows / 8), g_screen != 0,
-                            (unsigned long long *)dev_verify, st));
+  const int owned_tile_rows = owned * (band_rows / 8);
+  // Bounces exist only where a material asks for them.
+  const bool bounces = fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph) && !dev_verify;
+  rt::BounceDev bd;
+  memset(&bd, 0, sizeof bd);
+  bd.max_depth = 1;
+  if (bounces) {
+    rc = ensure_bounce_buffers(S, (size_t)fr->w * fr->h,
+                               (size_t)owned_tile_rows * 8 * fr->w);
+    if (rc)
+      return rc;
+    HIP_TRY(hipMemsetAsync(S->counts.p, 0, 65 * sizeof(uint32_t), st));
+    bd.max_depth = fr->max_depth;
+    bd.extra = S->extra.p;
+    bd.out = queue_for_level(S, 2);
+  }
+  const rt::SceneDev sd = S->dev();
+  HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, owned_tile_rows,
+                            g_screen != 0, (unsigned long long *)dev_verify, st));
+  if (bounces) {
+    for (int level = 2; level <= fr->max_depth; level++) {
+      bd.in = queue_for_level(S, level);
+      bd.out = queue_for_level(S, level + 1);
+      HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count, kBounceBlocks, st));
+    }
+    HIP_TRY(rt::launch_compose(fr->dev_fb, S->extra.p, (size_t)fr->w * fr->h, st));
+  }
   return RT_OK;
 }
 
@@ -318,6 +391,19 @@ int rt_render_device_selfcheck(rt_scene *S, const camera *cam, const rt_frame *f
   if (!dev_stats)
     return fail(RT_ERR_BAD_ARG, "dev_stats is NULL");
   return render_device_impl(S, cam, fr, dev_ray_count, dev_stats);
+}
+
+int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {
+  if (!S || !overflowed)
+    return fail(RT_ERR_BAD_ARG, "scene or result is NULL");
+  *overflowed = 0;
+  if (!S->counts.p)
+    return RT_OK;
+  uint32_t flag = 0;
+  HIP_TRY(hipSetDevice(S->device));
+  HIP_TRY(hipMemcpy(&flag, S->counts.p + 64, sizeof flag, hipMemcpyDeviceToHost));
+  *overflowed = flag != 0;
+  return RT_OK;
 }
 
 void rt_set_screen(int enabled) { g_screen = enabled; }
@@ -363,6 +449,11 @@ int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
       HIP_TRY(hipMemcpy(hit_ids, ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (n_rays)
       HIP_TRY(hipMemcpy(n_rays, cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    int over = 0;
+    if ((r = rt_scene_queue_overflowed(S, &over)))
+      return r;
+    if (over)
+      return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
     return RT_OK;
   };
   rc = body();

@@ -251,9 +251,12 @@ struct Beam {
 
 #define RT_SCREEN_EPS 1.52587890625e-05f /* 2^-16 */
 
+// delta = D * delta_scale: 2^-20 when every line passes through the apex up to
+// the rounding of its direction, slightly more than 1 when the apex is merely a
+// point near the ray origins (then a line misses it by at most |o - X|).
 __device__ __forceinline__ Beam make_beam(bool lv, float a, float dx, float dy,
                                           float dz, float Xx, float Xy, float Xz,
-                                          float Dk) {
+                                          float Dk, float delta_scale) {
   Beam B;
   B.Xx = Xx;
   B.Xy = Xy;
@@ -277,7 +280,7 @@ __device__ __forceinline__ Beam make_beam(bool lv, float a, float dx, float dy,
   B.sin_a = fmaf(sqrtf(s2), 1.000003814697265625f, 9.5367431640625e-07f);
   B.cos_a = sqrtf(1.0f - s2) * 0.999996185302734375f;
   B.K = fmaf(2.0f * RT_SCREEN_EPS * D, D, 8.271806125530277e-25f); // + 2^-80
-  B.delta = D * 9.5367431640625e-07f;                               // 2^-20
+  B.delta = D * delta_scale;
   B.narrow = !__any(bad) && s2 < 0.25f && n2 > 0.f && D < 1.8446744e19f;
   return B;
 }
@@ -305,9 +308,11 @@ __device__ __forceinline__ bool beam_keeps(const Beam &B, float4 g) {
 // ANY_HIT : only "is anything hit" is wanted (shadow rays, renderer.cpp:119);
 //           the loop may stop as soon as every live lane has a hit, which
 //           cannot change the answer.
-// BEAM    : the wave's rays share the apex (Xx,Xy,Xz) (the eye, or the light a
-//           shadow ray aims at) and are screened as described above; Dk is the
-//           lane's distance from its ray origin to the apex.
+// BEAM    : 0 = no screen.  1 = the wave's rays share the apex (Xx,Xy,Xz) (the
+//           eye, or the light a shadow ray aims at); Dk is the lane's distance
+//           from its ray origin to the apex.  2 = bounce rays: no common point,
+//           the apex is the mean ray origin and every line is within |o - X| of
+//           the parallel line through it.
 //
 // Nearest is by |P| from the WORLD origin with strict '>' (lowest index wins in
 // a class); between classes a triangle wins ties ('<=', renderer.cpp:181).  A
@@ -324,7 +329,11 @@ struct ScreenStats { // filled only by the verification build of the kernels
   unsigned long long *kept;
 };
 
-template <bool FROM_EYE, bool ANY_HIT, bool BEAM, bool VERIFY = false>
+#define RT_BEAM_NONE 0
+#define RT_BEAM_APEX 1
+#define RT_BEAM_MEAN 2
+
+template <bool FROM_EYE, bool ANY_HIT, int BEAM, bool VERIFY = false>
 __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                                      float oy, float oz, float dx, float dy,
                                      float dz, float Xx = 0.f, float Xy = 0.f,
@@ -360,11 +369,23 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   bool seek = live && !(ANY_HIT && idx_t >= 0);
 
   bool screened = false;
-  if (BEAM) {
+  if (BEAM != RT_BEAM_NONE) {
     // rays with a == 0 or NaN never yield an accepted sphere hit (see above)
     const bool lv = seek && (a > 0.f);
     if (__any(lv)) {
-      const Beam B = make_beam(lv, a, dx, dy, dz, Xx, Xy, Xz, Dk);
+      float dscale = 9.5367431640625e-07f; // 2^-20
+      if (BEAM == RT_BEAM_MEAN) {
+        const float inv_n = 1.0f / (float)__builtin_popcountll(__ballot(lv));
+        Xx = uniform(wave_sum(lv ? ox : 0.f) * inv_n);
+        Xy = uniform(wave_sum(lv ? oy : 0.f) * inv_n);
+        Xz = uniform(wave_sum(lv ? oz : 0.f) * inv_n);
+        float ex = ox - Xx, ey = oy - Xy, ez = oz - Xz;
+        // |o - X|, rounded up: one-sided by (1+2^-18) and an absolute 2^-30
+        Dk = fmaf(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))), 1.000003814697265625f,
+                  9.313225746154785e-10f);
+        dscale = 1.000003814697265625f;
+      }
+      const Beam B = make_beam(lv, a, dx, dy, dz, Xx, Xy, Xz, Dk, dscale);
       if (B.narrow) {
         screened = true;
         const int lane = threadIdx.x & 63;

@@ -37,6 +37,22 @@ struct FrameDev {
   int band_rows, band_index, band_count;
 };
 
+// Bounce-ray queue in HBM: two float4 per ray,
+//   (origin.xyz, weight) and (dir.xyz, bits of (pixel << 6 | depth)).
+struct RayQueue {
+  float4 *items;
+  uint32_t *count;    // rays appended (may exceed capacity: the excess is dropped)
+  uint32_t capacity;
+  uint32_t *overflow; // set to 1 when a ray had to be dropped
+};
+
+struct BounceDev {
+  RayQueue in;     // rays to trace at this level (unused by k_render)
+  RayQueue out;    // rays spawned for the next level
+  uint32_t *extra; // 3 x uint32 per pixel: integer light of bounce hits
+  int max_depth;   // 1 = no bounces (all other fields may be null)
+};
+
 struct CheckArgs {
   long n;
   const float *orig;
@@ -53,8 +69,13 @@ hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st);
 // discriminant test passes (must stay 0), spheres kept}; selects a slow
 // self-checking build of the kernel.
 hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
-                         const FrameDev &f, int owned_tile_rows, bool beam,
+                         const FrameDev &f, const BounceDev &bd,
+                         int owned_tile_rows, bool beam,
                          unsigned long long *verify_stats, hipStream_t st);
+hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
+                         uint64_t *ray_count, int blocks, hipStream_t st);
+hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
+                          hipStream_t st);
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);
 
 } // namespace rt

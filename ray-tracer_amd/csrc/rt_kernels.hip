@@ -157,6 +157,180 @@ __device__ __forceinline__ float phong_light(const Surface &s, const Hit &h,
 }
 
 // ---------------------------------------------------------------------------
+// Material bounces (an extension; the reference has none)
+// ---------------------------------------------------------------------------
+// A hit on a primitive with material (kr, kt, ior) at path weight w:
+//   - its Phong light is weighted by wl = w * ((1 - kr) - kt)
+//   - if depth < max_depth and w*kr >= 2^-8: a mirror ray from P along
+//     normalize(reflect(dir, n)), weight w*kr
+//   - if depth < max_depth and w*kt >= 2^-8: a refracted ray (Snell; total
+//     internal reflection falls back to the mirror direction), weight w*kt
+// The primary hit accumulates into the pixel as renderer.cpp:121-126 does.
+// Every later hit adds trunc(fColor*angle*wl) as an integer and the pixel is the
+// saturating sum, so the order in which bounce rays are processed cannot change
+// the image: they are appended to a ray queue in HBM and each bounce level runs
+// as its own launch with one queued ray per lane (all lanes busy, whatever the
+// depth of the individual paths).  Anything lighter than 2^-8 cannot reach one
+// LSB, so dropping it is exact.
+#define RT_MIN_WEIGHT 0.00390625f
+
+__device__ __forceinline__ float4 material_at(const SceneDev &sc, const Hit &h) {
+  if (h.kind == 1)
+    return sc.mat_tri ? sc.mat_tri[h.index] : make_float4(0.f, 0.f, 0.f, 0.f);
+  return sc.mat_sph ? sc.mat_sph[h.index] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void refract3(float dx, float dy, float dz, float nx,
+                                         float ny, float nz, float ior, float &rx,
+                                         float &ry, float &rz) {
+  float cosi = -dot3(dx, dy, dz, nx, ny, nz);
+  float mx = nx, my = ny, mz = nz, eta;
+  if (cosi < 0) { // leaving the medium
+    mx = -nx;
+    my = -ny;
+    mz = -nz;
+    cosi = -cosi;
+    eta = ior;
+  } else {
+    eta = 1.0f / ior;
+  }
+  float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+  if (k < 0) {
+    reflect3(dx, dy, dz, nx, ny, nz, rx, ry, rz);
+  } else {
+    float f = eta * cosi - sqrtf(k);
+    rx = eta * dx + f * mx;
+    ry = eta * dy + f * my;
+    rz = eta * dz + f * mz;
+  }
+  normalize3(rx, ry, rz);
+}
+
+// Wave-aggregated append: one atomic per wave, lanes write consecutive slots.
+__device__ __forceinline__ void queue_push(const RayQueue &q, bool want, float ox,
+                                           float oy, float oz, float dx, float dy,
+                                           float dz, float w, uint32_t pixel,
+                                           uint32_t depth) {
+  const unsigned long long m = __ballot(want);
+  if (!m)
+    return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(m);
+  uint32_t base = 0;
+  if (lane == leader)
+    base = atomicAdd(q.count, (uint32_t)__builtin_popcountll(m));
+  base = __builtin_amdgcn_readlane(base, leader);
+  if (want) {
+    const uint32_t slot = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (slot < q.capacity) {
+      q.items[2 * (size_t)slot] = make_float4(ox, oy, oz, w);
+      q.items[2 * (size_t)slot + 1] =
+          make_float4(dx, dy, dz, __uint_as_float((pixel << 6) | depth));
+    } else {
+      *q.overflow = 1u;
+    }
+  }
+}
+
+// Shade the hits of one wave (renderer.cpp:62-128) and queue their bounces.
+// PRIMARY: the hit of the pixel's own ray; light is accumulated into fb0..2 with
+// the reference's float form.  Otherwise light is added to the pixel's integer
+// side sums.  Returns the number of shadow rays this lane traced.
+template <bool PRIMARY, bool MATERIALS, int BEAM, bool VERIFY>
+__device__ __forceinline__ uint32_t
+shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
+           float dx, float dy, float dz, float w, uint32_t pixel, uint32_t depth,
+           uint32_t &fb0, uint32_t &fb1, uint32_t &fb2, ScreenStats st) {
+  uint32_t n_rays = 0;
+  if (!__any(hit))
+    return 0;
+  Surface s;
+  float kr = 0.f, kt = 0.f, ior = 1.f, wl = w;
+  if (hit) {
+    s = surface_at(sc, h);
+    if (MATERIALS) {
+      float4 m = material_at(sc, h);
+      kr = m.x;
+      kt = m.y;
+      ior = m.z > 0.f ? m.z : 1.0f;
+      wl = w * ((1.0f - kr) - kt);
+    }
+  }
+  const bool lit = hit && (PRIMARY || wl >= RT_MIN_WEIGHT);
+  if (__any(lit)) {
+    for (int l = 0; l < sc.l_size; l++) { // renderer.cpp:82
+      float fColor[3] = {0, 0, 0};
+      float lx = 0, ly = 0, lz = 0, angle = 0, dist = 0;
+      const float4 light = sc.lights[l];
+      if (lit) {
+        angle = phong_light(s, h, dx, dy, dz, light, fColor, lx, ly, lz);
+        dist = length3(light.x - h.Px, light.y - h.Py, light.z - h.Pz);
+      }
+      // renderer.cpp:119: shadow ray from exactly P, no distance limit.  All
+      // shadow rays of the wave aim at the light: that is the beam's apex.
+      Hit sh = trace<false, true, BEAM, VERIFY>(sc, lit, h.Px, h.Py, h.Pz, lx, ly,
+                                                lz, light.x, light.y, light.z,
+                                                dist, st);
+      if (lit) {
+        n_rays++;
+        if (sh.kind == 0) {
+          float a0 = fColor[0] * angle, a1 = fColor[1] * angle, a2 = fColor[2] * angle;
+          if (MATERIALS) {
+            a0 *= wl;
+            a1 *= wl;
+            a2 *= wl;
+          }
+          if (PRIMARY) {
+            fb0 = accumulate_u8(fb0, a0);
+            fb1 = accumulate_u8(fb1, a1);
+            fb2 = accumulate_u8(fb2, a2);
+          } else {
+            uint32_t c0 = (uint32_t)a0, c1 = (uint32_t)a1, c2 = (uint32_t)a2;
+            if (c0)
+              atomicAdd(bd.extra + 3 * (size_t)pixel + 0, c0);
+            if (c1)
+              atomicAdd(bd.extra + 3 * (size_t)pixel + 1, c1);
+            if (c2)
+              atomicAdd(bd.extra + 3 * (size_t)pixel + 2, c2);
+          }
+        }
+      }
+    }
+  }
+  if (MATERIALS) {
+    const bool deeper = hit && (int)depth < bd.max_depth;
+    const bool want_t = deeper && kt > 0.f && (w * kt >= RT_MIN_WEIGHT);
+    const bool want_r = deeper && kr > 0.f && (w * kr >= RT_MIN_WEIGHT);
+    if (__any(want_t)) {
+      float rx = 0, ry = 0, rz = 0;
+      if (want_t)
+        refract3(dx, dy, dz, s.nx, s.ny, s.nz, ior, rx, ry, rz);
+      queue_push(bd.out, want_t, h.Px, h.Py, h.Pz, rx, ry, rz, w * kt, pixel, depth + 1);
+    }
+    if (__any(want_r)) {
+      float rx = 0, ry = 0, rz = 0;
+      if (want_r) {
+        reflect3(dx, dy, dz, s.nx, s.ny, s.nz, rx, ry, rz);
+        normalize3(rx, ry, rz);
+      }
+      queue_push(bd.out, want_r, h.Px, h.Py, h.Pz, rx, ry, rz, w * kr, pixel, depth + 1);
+    }
+  }
+  return n_rays;
+}
+
+__device__ __forceinline__ void add_ray_count(uint64_t *counter, uint32_t n) {
+  if (!counter)
+    return;
+  uint32_t v = n; // wave sum, then one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v)
+    atomicAdd(reinterpret_cast<unsigned long long *>(counter), (unsigned long long)v);
+}
+
+// ---------------------------------------------------------------------------
 // k_render
 // ---------------------------------------------------------------------------
 // Work decomposition: a wave owns an 8x8 pixel tile (lane = 8*row + col inside
@@ -164,9 +338,10 @@ __device__ __forceinline__ float phong_light(const Surface &s, const Hit &h,
 // block's pixel writes cover 128 contiguous bytes per row.  blockIdx.y counts
 // the tile rows this call owns; bands of band_rows rows are dealt round-robin
 // over band_count callers (row sharding, renderer.cpp:27-28).
-template <bool BEAM, bool VERIFY>
+template <bool BEAM, bool VERIFY, bool MATERIALS>
 __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
-                                                FrameDev f, ScreenStats st) {
+                                                FrameDev f, BounceDev bd,
+                                                ScreenStats st) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int tiles_per_band = f.band_rows >> 3;
@@ -184,44 +359,19 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
   float dx = px - cam.ox, dy = py - cam.oy, dz = cam.plane_z - cam.oz;
   normalize3(dx, dy, dz);
 
-  Hit h = trace<true, false, BEAM, VERIFY>(sc, inside, cam.ox, cam.oy, cam.oz,
-                                           dx, dy, dz, cam.ox, cam.oy, cam.oz,
-                                           0.f, st);
+  constexpr int BM = BEAM ? RT_BEAM_APEX : RT_BEAM_NONE;
+  Hit h = trace<true, false, BM, VERIFY>(sc, inside, cam.ox, cam.oy, cam.oz, dx,
+                                         dy, dz, cam.ox, cam.oy, cam.oz, 0.f, st);
 
   uint32_t fb0 = 0, fb1 = 0, fb2 = 0; // renderer.cpp:50-52
   uint32_t n_rays = inside ? 1u : 0u;
   const bool hit = inside && h.kind != 0;
+  const size_t p = (size_t)f.w * (inside ? i : 0) + (inside ? j : 0);
 
-  if (__any(hit)) {
-    Surface s;
-    if (hit)
-      s = surface_at(sc, h);
-    for (int l = 0; l < sc.l_size; l++) { // renderer.cpp:82
-      float fColor[3] = {0, 0, 0};
-      float lx = 0, ly = 0, lz = 0, angle = 0, dist = 0;
-      const float4 light = sc.lights[l];
-      if (hit) {
-        angle = phong_light(s, h, dx, dy, dz, light, fColor, lx, ly, lz);
-        dist = length3(light.x - h.Px, light.y - h.Py, light.z - h.Pz);
-      }
-      // renderer.cpp:119: shadow ray from exactly P, no distance limit.  All
-      // shadow rays of the wave aim at the light: that is the beam's apex.
-      Hit sh = trace<false, true, BEAM, VERIFY>(sc, hit, h.Px, h.Py, h.Pz, lx, ly,
-                                                lz, light.x, light.y, light.z,
-                                                dist, st);
-      if (hit) {
-        n_rays++;
-        if (sh.kind == 0) {
-          fb0 = accumulate_u8(fb0, fColor[0] * angle);
-          fb1 = accumulate_u8(fb1, fColor[1] * angle);
-          fb2 = accumulate_u8(fb2, fColor[2] * angle);
-        }
-      }
-    }
-  }
+  n_rays += shade_hits<true, MATERIALS, BM, VERIFY>(sc, bd, hit, h, dx, dy, dz, 1.0f,
+                                                    (uint32_t)p, 1u, fb0, fb1, fb2, st);
 
   if (inside) {
-    size_t p = (size_t)f.w * i + j;
     uchar4 o;
     o.x = (unsigned char)fb0;
     o.y = (unsigned char)fb1;
@@ -231,17 +381,65 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
     if (f.ids)
       f.ids[p] = h.kind == 0 ? -1 : (h.kind == 1 ? h.index : sc.t_size + h.index);
   }
+  add_ray_count(f.ray_count, n_rays);
+}
 
-  if (f.ray_count) {
-    // wave sum, then one atomic per wave
-    uint32_t v = n_rays;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-      v += __shfl_down(v, off, 64);
-    if (lane == 0 && v)
-      atomicAdd(reinterpret_cast<unsigned long long *>(f.ray_count),
-                (unsigned long long)v);
+// ---------------------------------------------------------------------------
+// k_bounce — one bounce level: one queued ray per lane
+// ---------------------------------------------------------------------------
+// The grid is fixed; waves stride over the queue, whose length is read from
+// device memory (the host never waits for it).
+template <bool BEAM>
+__global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
+                                                uint64_t *ray_count) {
+  uint32_t n_in = *bd.in.count;
+  if (n_in > bd.in.capacity)
+    n_in = bd.in.capacity;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+  constexpr int BM = BEAM ? RT_BEAM_MEAN : RT_BEAM_NONE;
+  constexpr int BS = BEAM ? RT_BEAM_APEX : RT_BEAM_NONE;
+  uint32_t n_rays = 0;
+  for (uint32_t base = first; base < n_in; base += stride) {
+    const uint32_t r = base + (threadIdx.x & 63);
+    const bool live = r < n_in;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (live) {
+      a = bd.in.items[2 * (size_t)r];
+      b = bd.in.items[2 * (size_t)r + 1];
+    }
+    const uint32_t tag = __float_as_uint(b.w);
+    const uint32_t pixel = tag >> 6, depth = tag & 63u;
+    Hit h = trace<false, false, BM, false>(sc, live, a.x, a.y, a.z, b.x, b.y, b.z);
+    if (live)
+      n_rays++;
+    const bool hit = live && h.kind != 0;
+    uint32_t u0 = 0, u1 = 0, u2 = 0;
+    n_rays += shade_hits<false, true, BS, false>(sc, bd, hit, h, b.x, b.y, b.z, a.w, pixel,
+                                                 depth, u0, u1, u2,
+                                                 ScreenStats{nullptr, nullptr});
   }
+  add_ray_count(ray_count, n_rays);
+}
+
+// Pixel = saturating sum of the primary hit's light (already in fb) and the
+// integer side sums of all bounce hits; the side sums are cleared for reuse.
+__global__ void k_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels) {
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pixels)
+    return;
+  uint32_t e0 = extra[3 * p], e1 = extra[3 * p + 1], e2 = extra[3 * p + 2];
+  if ((e0 | e1 | e2) == 0)
+    return;
+  uchar4 c = reinterpret_cast<uchar4 *>(fb)[p];
+  uint32_t v0 = c.x + e0, v1 = c.y + e1, v2 = c.z + e2;
+  c.x = (unsigned char)(v0 > 255u ? 255u : v0);
+  c.y = (unsigned char)(v1 > 255u ? 255u : v1);
+  c.z = (unsigned char)(v2 > 255u ? 255u : v2);
+  reinterpret_cast<uchar4 *>(fb)[p] = c;
+  extra[3 * p] = 0;
+  extra[3 * p + 1] = 0;
+  extra[3 * p + 2] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -253,7 +451,7 @@ __global__ __launch_bounds__(256) void k_check(SceneDev sc, CheckArgs a) {
   long rr = live ? r : 0;
   float ox = a.orig[3 * rr], oy = a.orig[3 * rr + 1], oz = a.orig[3 * rr + 2];
   float dx = a.dir[3 * rr], dy = a.dir[3 * rr + 1], dz = a.dir[3 * rr + 2];
-  Hit h = trace<false, false, false>(sc, live, ox, oy, oz, dx, dy, dz);
+  Hit h = trace<false, false, RT_BEAM_NONE>(sc, live, ox, oy, oz, dx, dy, dz);
   if (live) {
     a.kind[r] = h.kind;
     a.index[r] = h.index;
@@ -283,21 +481,43 @@ hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
-                         const FrameDev &f, int owned_tile_rows, bool beam,
+                         const FrameDev &f, const BounceDev &bd,
+                         int owned_tile_rows, bool beam,
                          unsigned long long *verify_stats, hipStream_t st) {
   if (owned_tile_rows <= 0)
     return hipSuccess;
   dim3 grid((f.w + 31) / 32, owned_tile_rows);
   ScreenStats ss{nullptr, nullptr};
+  const bool mats = bd.max_depth > 1;
   if (verify_stats) {
     ss.dropped_but_candidate = verify_stats;
     ss.kept = verify_stats + 1;
-    hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, st, sc, cam, f, ss);
+    hipLaunchKernelGGL((k_render<true, true, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
+  } else if (beam && mats) {
+    hipLaunchKernelGGL((k_render<true, false, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
   } else if (beam) {
-    hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, st, sc, cam, f, ss);
+    hipLaunchKernelGGL((k_render<true, false, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
+  } else if (mats) {
+    hipLaunchKernelGGL((k_render<false, false, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
   } else {
-    hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, st, sc, cam, f, ss);
+    hipLaunchKernelGGL((k_render<false, false, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
+                         uint64_t *ray_count, int blocks, hipStream_t st) {
+  if (beam)
+    hipLaunchKernelGGL((k_bounce<true>), dim3(blocks), dim3(256), 0, st, sc, bd, ray_count);
+  else
+    hipLaunchKernelGGL((k_bounce<false>), dim3(blocks), dim3(256), 0, st, sc, bd, ray_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_compose, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0,
+                     st, fb, extra, n_pixels);
   return hipGetLastError();
 }
 

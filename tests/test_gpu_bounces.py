@@ -1,0 +1,127 @@
+"""max_depth > 1: material bounces.  The reference has no such thing
+(renderer.cpp traces one primary and one shadow ray per light), so the only
+comparator is the CPU oracle's definition of the extension: PARITY UNPINNED by
+the reference beyond depth 1.  What IS pinned: with all-zero materials, or
+max_depth = 1, the result equals the reference's golden output bit for bit.
+
+GPU and oracle must agree exactly: framebuffer, ids and ray counts.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_scenes
+import rtamd
+
+pytestmark = pytest.mark.gpu
+
+
+def row_crc(a):
+    a = np.ascontiguousarray(a)
+    return np.array([zlib.crc32(a[i].tobytes()) for i in range(a.shape[0])], np.uint32)
+
+
+def random_materials(n, seed):
+    rng = np.random.RandomState(seed)
+    m = np.zeros((n, 4), np.float32)
+    cls = rng.randint(0, 4, n)
+    m[cls == 1, 0] = rng.uniform(0.2, 0.9, (cls == 1).sum())            # mirrors
+    m[cls == 2, 0] = 0.1                                                # glass
+    m[cls == 2, 1] = rng.uniform(0.5, 0.85, (cls == 2).sum())
+    m[cls == 2, 2] = rng.uniform(1.1, 2.0, (cls == 2).sum())
+    m[cls == 3, 0] = 0.5                                                # both, ior 1
+    m[cls == 3, 1] = 0.5
+    m[cls == 3, 2] = 1.0
+    return m
+
+
+def material_scene(seed, **kw):
+    sc = golden_scenes.mixed_scene(seed=seed, **kw)
+    sc.mat_sphere = random_materials(sc.s_size, seed + 100)
+    sc.mat_tri = random_materials(sc.t_size, seed + 200)
+    return sc
+
+
+def compare(sc, w, h, depth, oracle, rows=None):
+    fb, ids, n = rtamd.render(sc, w, h, max_depth=depth)
+    fo, io, no = oracle.render(sc, w, h, max_depth=depth, rows=rows)
+    if rows is None:
+        sel = slice(None)
+    else:
+        sel = slice(rows[0], rows[1], rows[2])
+    assert np.array_equal(ids[sel], io[sel])
+    bad = (fb[sel] != fo[sel]).any(-1)
+    assert not bad.any(), f"{int(bad.sum())} pixels differ at depth {depth}; first " \
+        f"{np.argwhere(bad)[:3].tolist()}"
+    if rows is None:
+        assert n == no
+    return fb, n
+
+
+@pytest.mark.parametrize("depth", [2, 3, 8])
+def test_mixed_scene_depths(oracle, depth):
+    sc = material_scene(51, n_spheres=60, n_tris=10, n_lights=2)
+    compare(sc, 480, 270, depth, oracle)
+
+
+def test_ray_count_grows_with_depth_then_saturates(oracle):
+    sc = material_scene(52)
+    counts = [rtamd.render(sc, 320, 180, max_depth=d, want_ids=False)[2] for d in (1, 2, 4, 8, 16)]
+    assert counts[0] < counts[1] <= counts[2] <= counts[3] <= counts[4]
+    # weights shrink below 2^-8 eventually: deeper limits add nothing
+    assert rtamd.render(sc, 320, 180, max_depth=40, want_ids=False)[2] == \
+        rtamd.render(sc, 320, 180, max_depth=63, want_ids=False)[2]
+
+
+def test_zero_materials_any_depth_is_the_reference(golden):
+    sc = golden_scenes.full_frame_scenes()["mixed"]
+    sc.mat_sphere = np.zeros((sc.s_size, 4), np.float32)
+    sc.mat_tri = np.zeros((sc.t_size, 4), np.float32)
+    fb, ids, n = rtamd.render(sc, 2560, 1440, max_depth=8)
+    assert np.array_equal(row_crc(fb), golden["mixed_fbcrc"])
+    assert np.array_equal(row_crc(ids), golden["mixed_idcrc"])
+
+
+def test_materials_are_ignored_at_depth_1(oracle):
+    """max_depth = 1 is the reference's renderer whatever the materials say."""
+    sc = material_scene(53)
+    fb, n = compare(sc, 400, 240, 1, oracle)
+    plain = golden_scenes.mixed_scene(seed=53)
+    fb0, _, n0 = rtamd.render(plain, 400, 240, max_depth=1)
+    assert np.array_equal(fb, fb0) and n == n0
+
+
+def test_1k_grid_1080p_depth4(oracle):
+    """The 1k-sphere configuration: 32x32 grid, 1920x1080, depth 4, seeded
+    materials (one third diffuse / mirror / glass)."""
+    sc = rtamd.material_grid_scene(32, 32)
+    compare(sc, 1920, 1080, 4, oracle)
+
+
+def test_10k_grid_4k_depth8_row_sample(oracle):
+    """The 10k-sphere configuration at full size on the GPU; the oracle checks
+    every 72nd row (30 rows) of it."""
+    sc = rtamd.material_grid_scene(100, 100)
+    compare(sc, 3840, 2160, 8, oracle, rows=(36, 2160, 72))
+
+
+def test_screen_off_gives_the_same_bounces(oracle):
+    sc = material_scene(54, n_spheres=120)
+    try:
+        rtamd.set_screen(False)
+        fb0, _, n0 = rtamd.render(sc, 320, 200, max_depth=6)
+    finally:
+        rtamd.set_screen(True)
+    fb1, _, n1 = rtamd.render(sc, 320, 200, max_depth=6)
+    assert np.array_equal(fb0, fb1) and n0 == n1
+
+
+def test_invalid_materials_rejected():
+    sc = golden_scenes.mixed_scene()
+    sc.mat_sphere = np.zeros((sc.s_size, 4), np.float32)
+    sc.mat_sphere[3] = [0.7, 0.6, 1.5, 0]
+    with pytest.raises(rtamd.RtError):
+        rtamd.render(sc, 32, 32, max_depth=3)
+    with pytest.raises(rtamd.RtError):
+        rtamd.render(golden_scenes.mixed_scene(), 32, 32, max_depth=64)
