@@ -66,6 +66,10 @@ struct rt_scene {
   DevBuf<float4> sph_geo, sph_prim, lights, mat_tri, mat_sph;
   DevBuf<rt::TriRec> tri;
   DevBuf<uchar4> col_tri, col_sph;
+  DevBuf<rt::BvhNode> bvh;
+  DevBuf<float4> leaf_geo;
+  DevBuf<int32_t> leaf_idx;
+  bool has_bvh = false;
   bool has_mat_tri = false, has_mat_sph = false;
   bool eye_valid = false;
   float eye[3] = {0, 0, 0};
@@ -89,6 +93,10 @@ struct rt_scene {
     d.s_size = s_size;
     d.s_pad = s_pad;
     d.l_size = l_size;
+    const bool use_bvh = has_bvh && g_screen != 0;
+    d.bvh = use_bvh ? bvh.p : nullptr;
+    d.leaf_geo = use_bvh ? leaf_geo.p : nullptr;
+    d.leaf_idx = use_bvh ? leaf_idx.p : nullptr;
     return d;
   }
 };
@@ -196,6 +204,21 @@ int scene_build(rt_scene *S, const scene_desc *s) {
   a.col_tri = S->col_tri.p;
   a.col_sph = S->col_sph.p;
   HIP_TRY(rt::launch_prep_scene(a, nullptr));
+
+  // sphere hierarchy for rays that do not come in bundles
+  {
+    rt::BvhHost H;
+    rt::bvh_build(s->spheres, s->radius, s->s_size, H);
+    S->has_bvh = H.valid;
+    if (H.valid) {
+      if ((rc = upload(S->bvh, H.nodes.data(), H.nodes.size())) ||
+          (rc = upload(S->leaf_idx, H.leaf_idx.data(), H.leaf_idx.size())))
+        return rc;
+      HIP_TRY(S->leaf_geo.alloc(H.leaf_idx.size()));
+      HIP_TRY(rt::launch_gather_leaves(S->sph_geo.p, S->leaf_idx.p, S->leaf_geo.p,
+                                       (int)H.leaf_idx.size(), nullptr));
+    }
+  }
   HIP_TRY(hipStreamSynchronize(nullptr)); // staging buffers die here
   S->eye_valid = false;
   return RT_OK;

@@ -1,0 +1,123 @@
+// rt_bvh.cpp — host-side construction of the bounding-sphere hierarchy
+// (median split on the longest axis of the centres' bounding box).
+#include "rt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace rt {
+namespace {
+
+struct Builder {
+  const float *c;
+  const float *r;
+  std::vector<int32_t> order;
+  BvhHost *out;
+
+  // Smallest float >= x.
+  static float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x)
+      f = std::nextafter(f, INFINITY);
+    return f;
+  }
+
+  // Bounding sphere of order[b, e): centre of the centres' box, radius covering
+  // every member sphere entirely, rounded outwards.
+  float4 bound(int b, int e, int &axis) const {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = b; k < e; k++)
+      for (int d = 0; d < 3; d++) {
+        double v = c[3 * order[k] + d];
+        lo[d] = std::min(lo[d], v);
+        hi[d] = std::max(hi[d], v);
+      }
+    double mid[3];
+    axis = 0;
+    for (int d = 0; d < 3; d++) {
+      mid[d] = 0.5 * (lo[d] + hi[d]);
+      if (hi[d] - lo[d] > hi[axis] - lo[axis])
+        axis = d;
+    }
+    float cf[3] = {(float)mid[0], (float)mid[1], (float)mid[2]};
+    double R = 0;
+    for (int k = b; k < e; k++) {
+      const float *p = c + 3 * order[k];
+      double dx = p[0] - (double)cf[0], dy = p[1] - (double)cf[1], dz = p[2] - (double)cf[2];
+      R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)r[order[k]]));
+    }
+    return make_float4(cf[0], cf[1], cf[2], round_up(R * (1.0 + 1e-6)));
+  }
+
+  // Returns the link for order[b, e) and its bounding sphere.
+  int32_t build(int b, int e, float4 &sphere) {
+    int axis;
+    sphere = bound(b, e, axis);
+    const int n = e - b;
+    if (n <= BVH_LEAF_MAX) {
+      const int first = (int)out->leaf_idx.size();
+      for (int k = b; k < e; k++)
+        out->leaf_idx.push_back(order[k]);
+      return ~((first << 3) | (n - 1));
+    }
+    const int m = b + n / 2;
+    std::nth_element(order.begin() + b, order.begin() + m, order.begin() + e,
+                     [&](int32_t x, int32_t y) {
+                       float vx = c[3 * x + axis], vy = c[3 * y + axis];
+                       return vx < vy || (vx == vy && x < y);
+                     });
+    const int me = (int)out->nodes.size();
+    out->nodes.push_back(BvhNode{});
+    float4 s0, s1;
+    int32_t l0 = build(b, m, s0);
+    int32_t l1 = build(m, e, s1);
+    BvhNode &N = out->nodes[me];
+    N.s0 = s0;
+    N.s1 = s1;
+    N.link0 = l0;
+    N.link1 = l1;
+    N.pad0 = N.pad1 = 0;
+    return me;
+  }
+};
+
+} // namespace
+
+void bvh_build(const float *spheres, const float *radius, int n, BvhHost &out) {
+  out.nodes.clear();
+  out.leaf_idx.clear();
+  out.valid = false;
+  if (n <= 0)
+    return;
+  for (int i = 0; i < n; i++)
+    if (!std::isfinite(spheres[3 * i]) || !std::isfinite(spheres[3 * i + 1]) ||
+        !std::isfinite(spheres[3 * i + 2]) || !std::isfinite(radius[i]) ||
+        std::fabs(spheres[3 * i]) > 1e18f || std::fabs(spheres[3 * i + 1]) > 1e18f ||
+        std::fabs(spheres[3 * i + 2]) > 1e18f || std::fabs(radius[i]) > 1e18f)
+      return;
+  Builder B;
+  B.c = spheres;
+  B.r = radius;
+  B.order.resize(n);
+  std::iota(B.order.begin(), B.order.end(), 0);
+  B.out = &out;
+  out.leaf_idx.reserve(n);
+  float4 root;
+  // node 0 is always the root; a scene that fits one leaf still gets a node
+  out.nodes.push_back(BvhNode{});
+  if (n <= BVH_LEAF_MAX) {
+    int32_t l = B.build(0, n, root);
+    out.nodes[0].s0 = root;
+    out.nodes[0].s1 = root;
+    out.nodes[0].link0 = l;
+    out.nodes[0].link1 = BVH_EMPTY;
+  } else {
+    out.nodes.pop_back();
+    int32_t l = B.build(0, n, root);
+    (void)l; // == 0: the first node pushed
+  }
+  out.valid = true;
+}
+
+} // namespace rt

@@ -1,0 +1,37 @@
+// rt_bvh.h — bounding-sphere hierarchy over the scene's spheres.
+//
+// Used for rays that do not travel in coherent bundles (bounce rays, bulk
+// check_intersection queries): each lane walks the tree for its own ray with a
+// small stack and runs the reference's arithmetic only on the spheres of the
+// leaves its line can touch.  Which spheres are tested changes, the result does
+// not: the nearest-hit rule "smallest |P|, lowest index on ties"
+// (renderer.cpp:168-177) does not depend on the order of the tests.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+namespace rt {
+
+// One inner node holds the bounding spheres of its two children, so a visit
+// costs one 48-byte load.  link >= 0: index of the child node.  link < 0: leaf,
+// ~link = (first << 3) | (count - 1) into the leaf arrays (count <= 8).
+struct BvhNode {
+  float4 s0, s1; // centre.xyz, radius (covers every member sphere entirely)
+  int32_t link0, link1;
+  int32_t pad0, pad1;
+};
+constexpr int32_t BVH_EMPTY = 0x7fffffff;
+constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_STACK = 40;
+
+struct BvhHost {
+  std::vector<BvhNode> nodes;
+  std::vector<int32_t> leaf_idx; // sphere index of each leaf slot
+  bool valid = false;            // false: scene has non-finite spheres, do not use
+};
+
+// spheres: 3*n floats, radius: n floats.
+void bvh_build(const float *spheres, const float *radius, int n, BvhHost &out);
+
+} // namespace rt

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rt_bvh.h"
+
 namespace rt {
 
 // ---- layout in HBM ----------------------------------------------------------
@@ -44,6 +46,10 @@ struct SceneDev {
   const float4 *mat_sph;
   const float4 *lights;  // xyz
   int t_size, s_size, s_pad, l_size;
+  // bounding-sphere hierarchy over the spheres (rt_bvh.h); bvh == nullptr: none
+  const BvhNode *bvh;
+  const float4 *leaf_geo;    // sph_geo gathered into leaf order
+  const int32_t *leaf_idx;   // original sphere index of each leaf slot
 };
 
 struct CameraDev {
@@ -230,7 +236,7 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
 // with L = o - c and |d|^2 = a, the float test passing implies
 //     dist(c, line)^2  <=  r^2 + 21 u (|L|^2 + r^2),     u = 2^-24
 // (3-term dot products contribute <= 3u relative to |d||L|, the remaining
-// products/sums u each).  The screen uses eps = 2^-16 = 64u in place of 21u and,
+// products/sums u each).  The screen uses eps = 2^-16 = 256u in place of 21u and,
 // for rays that only approximately pass through the apex X (shadow rays:
 // d = normalize(X - P) in float, angular error < 4u), widens the radius by
 // delta = 2^-20 * max|X - P|.  Its own float arithmetic is made one-sided:
@@ -308,6 +314,8 @@ __device__ __forceinline__ bool beam_keeps(const Beam &B, float4 g) {
 // ANY_HIT : only "is anything hit" is wanted (shadow rays, renderer.cpp:119);
 //           the loop may stop as soon as every live lane has a hit, which
 //           cannot change the answer.
+//           3 = no bundle at all: each lane walks the bounding-sphere hierarchy
+//           for its own ray (bvh_touches below).
 // BEAM    : 0 = no screen.  1 = the wave's rays share the apex (Xx,Xy,Xz) (the
 //           eye, or the light a shadow ray aims at); Dk is the lane's distance
 //           from its ray origin to the apex.  2 = bounce rays: no common point,
@@ -332,6 +340,28 @@ struct ScreenStats { // filled only by the verification build of the kernels
 #define RT_BEAM_NONE 0
 #define RT_BEAM_APEX 1
 #define RT_BEAM_MEAN 2
+#define RT_ACCEL_BVH 3
+
+// Can the line {o + t d} touch any sphere inside the bounding sphere s?  Must
+// say yes whenever the float discriminant test (maths.cpp:132-133) can pass for
+// a member sphere (centre c, radius r) of the node.  From the bound above,
+//   dist(c, line) <= r sqrt(1+64u) + sqrt(64u) |o - c|,  sqrt(64u) = 2^-9,
+// and |o - c| <= |M| + R, |c - centre| + r <= R with M = centre - o, so
+//   dist(centre, line) <= R (1 + 2^-9 + 2^-18) + 2^-9 |M|  =: Rtot.
+// dist^2 * a = a |M|^2 - (M.d)^2 is formed with |M|^2 deflated by (1-2^-19),
+// which exceeds the rounding of its five products and sums (and of using the
+// float a for |d|^2); Rtot is rounded outwards through its two coefficients.
+// NaN or inf anywhere answers yes.
+__device__ __forceinline__ bool bvh_touches(float4 s, float ox, float oy, float oz,
+                                            float dx, float dy, float dz, float a) {
+  float Mx = s.x - ox, My = s.y - oy, Mz = s.z - oz;
+  float m2 = fmaf(Mz, Mz, fmaf(My, My, Mx * Mx));
+  float md = fmaf(dz, Mz, fmaf(dy, My, dx * Mx));
+  float Rtot = fmaf(s.w, 1.002f, __builtin_amdgcn_sqrtf(m2) * 0.00196f);
+  float lhs = fmaf(-md, md, (a * m2) * 0.99999809265136719f);
+  float rhs = (a * Rtot) * (Rtot * 1.000001f);
+  return !(lhs > rhs);
+}
 
 template <bool FROM_EYE, bool ANY_HIT, int BEAM, bool VERIFY = false>
 __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
@@ -441,6 +471,68 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
       }
     } else {
       screened = true; // no lane can get a sphere hit
+    }
+  }
+
+  if (BEAM == RT_ACCEL_BVH && sc.bvh != nullptr) {
+    // Per-lane walk.  Rays with a == 0 / NaN never yield an accepted sphere hit;
+    // an a far outside [2^-40, 2^40] sends the whole wave to the plain loop.
+    const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
+    if (!__any(seek && a > 0.f && !sane)) {
+      screened = true;
+      if (seek && a > 0.f) {
+        int stack[BVH_STACK];
+        int sp = 0;
+        int node = 0;
+        bool done = false;
+        while (!done) {
+          const BvhNode N = sc.bvh[node];
+          int next = -1;
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const float4 s = c ? N.s1 : N.s0;
+            const int32_t link = c ? N.link1 : N.link0;
+            if (link == BVH_EMPTY || !bvh_touches(s, ox, oy, oz, dx, dy, dz, a))
+              continue;
+            if (link >= 0) {
+              if (next < 0)
+                next = link;
+              else if (sp < BVH_STACK)
+                stack[sp++] = link;
+            } else {
+              const int v = ~link, first = v >> 3, count = (v & 7) + 1;
+              for (int k = 0; k < count; k++) {
+                const float4 g = sc.leaf_geo[first + k];
+                float Px, Py, Pz;
+                if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz,
+                                 Px, Py, Pz)) {
+                  const float len = length3(Px, Py, Pz);
+                  const int idx = sc.leaf_idx[first + k];
+                  // renderer.cpp:170 scans in index order with a strict '>':
+                  // the smallest |P| wins and, among equals, the lowest index
+                  if (len < RT_INF && (len < len_s || (len == len_s && idx < idx_s))) {
+                    len_s = len;
+                    idx_s = idx;
+                    sPx = Px;
+                    sPy = Py;
+                    sPz = Pz;
+                    if (ANY_HIT)
+                      done = true;
+                  }
+                }
+              }
+            }
+          }
+          if (!done) {
+            if (next >= 0)
+              node = next;
+            else if (sp > 0)
+              node = stack[--sp];
+            else
+              done = true;
+          }
+        }
+      }
     }
   }
 

@@ -76,6 +76,8 @@ hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
                          uint64_t *ray_count, int blocks, hipStream_t st);
 hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
                           hipStream_t st);
+hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
+                                float4 *leaf_geo, int n, hipStream_t st);
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);
 
 } // namespace rt

@@ -397,8 +397,10 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
     n_in = bd.in.capacity;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
-  constexpr int BM = BEAM ? RT_BEAM_MEAN : RT_BEAM_NONE;
-  constexpr int BS = BEAM ? RT_BEAM_APEX : RT_BEAM_NONE;
+  // Bounce rays of one wave share neither an origin nor a direction: every
+  // lane walks the sphere hierarchy for its own ray, shadow rays included.
+  constexpr int BM = BEAM ? RT_ACCEL_BVH : RT_BEAM_NONE;
+  constexpr int BS = BEAM ? RT_ACCEL_BVH : RT_BEAM_NONE;
   uint32_t n_rays = 0;
   for (uint32_t base = first; base < n_in; base += stride) {
     const uint32_t r = base + (threadIdx.x & 63);
@@ -445,13 +447,15 @@ __global__ void k_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels) {
 // ---------------------------------------------------------------------------
 // k_check — bulk check_intersection (renderer.hpp:21-23)
 // ---------------------------------------------------------------------------
+template <bool ACCEL>
 __global__ __launch_bounds__(256) void k_check(SceneDev sc, CheckArgs a) {
   long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   bool live = r < a.n;
   long rr = live ? r : 0;
   float ox = a.orig[3 * rr], oy = a.orig[3 * rr + 1], oz = a.orig[3 * rr + 2];
   float dx = a.dir[3 * rr], dy = a.dir[3 * rr + 1], dz = a.dir[3 * rr + 2];
-  Hit h = trace<false, false, RT_BEAM_NONE>(sc, live, ox, oy, oz, dx, dy, dz);
+  Hit h = trace<false, false, ACCEL ? RT_ACCEL_BVH : RT_BEAM_NONE>(sc, live, ox, oy, oz,
+                                                                   dx, dy, dz);
   if (live) {
     a.kind[r] = h.kind;
     a.index[r] = h.index;
@@ -524,8 +528,27 @@ hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st) {
   if (a.n <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL(k_check, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0,
-                     st, sc, a);
+  const dim3 grid((unsigned)((a.n + 255) / 256));
+  if (sc.bvh)
+    hipLaunchKernelGGL((k_check<true>), grid, dim3(256), 0, st, sc, a);
+  else
+    hipLaunchKernelGGL((k_check<false>), grid, dim3(256), 0, st, sc, a);
+  return hipGetLastError();
+}
+
+__global__ void k_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
+                                float4 *leaf_geo, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    leaf_geo[i] = sph_geo[leaf_idx[i]];
+}
+
+hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
+                                float4 *leaf_geo, int n, hipStream_t st) {
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(k_gather_leaves, dim3((n + 255) / 256), dim3(256), 0, st, sph_geo,
+                     leaf_idx, leaf_geo, n);
   return hipGetLastError();
 }
 
