@@ -376,7 +376,7 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
                   : 0;
   const int owned_tile_rows = owned * (band_rows / 8);
   // Bounces exist only where a material asks for them.
-  const bool bounces = fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph) && !dev_verify;
+  const bool bounces = fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph);
   rt::BounceDev bd;
   memset(&bd, 0, sizeof bd);
   bd.max_depth = 1;
@@ -397,7 +397,8 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
     for (int level = 2; level <= fr->max_depth; level++) {
       bd.in = queue_for_level(S, level);
       bd.out = queue_for_level(S, level + 1);
-      HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count, kBounceBlocks, st));
+      HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count,
+                                (unsigned long long *)dev_verify, kBounceBlocks, st));
     }
     HIP_TRY(rt::launch_compose(fr->dev_fb, S->extra.p, (size_t)fr->w * fr->h, st));
   }

@@ -335,6 +335,7 @@ struct Hit {
 struct ScreenStats { // filled only by the verification build of the kernels
   unsigned long long *dropped_but_candidate;
   unsigned long long *kept;
+  unsigned long long *walk; // [0] rays walked, [1] node bounds tested, [2] leaf spheres tested
 };
 
 #define RT_BEAM_NONE 0
@@ -368,7 +369,7 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                                      float oy, float oz, float dx, float dy,
                                      float dz, float Xx = 0.f, float Xy = 0.f,
                                      float Xz = 0.f, float Dk = 0.f,
-                                     ScreenStats st = ScreenStats{nullptr, nullptr}) {
+                                     ScreenStats st = ScreenStats{nullptr, nullptr, nullptr}) {
   float len_t = RT_INF, len_s = RT_INF;
   int idx_t = -1, idx_s = -1;
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
@@ -399,7 +400,7 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   bool seek = live && !(ANY_HIT && idx_t >= 0);
 
   bool screened = false;
-  if (BEAM != RT_BEAM_NONE) {
+  if (BEAM == RT_BEAM_APEX || BEAM == RT_BEAM_MEAN) {
     // rays with a == 0 or NaN never yield an accepted sphere hit (see above)
     const bool lv = seek && (a > 0.f);
     if (__any(lv)) {
@@ -485,9 +486,11 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
         int sp = 0;
         int node = 0;
         bool done = false;
+        unsigned n_nodes = 0, n_leaf = 0;
         while (!done) {
           const BvhNode N = sc.bvh[node];
           int next = -1;
+          n_nodes += 2;
 #pragma unroll
           for (int c = 0; c < 2; c++) {
             const float4 s = c ? N.s1 : N.s0;
@@ -501,6 +504,7 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                 stack[sp++] = link;
             } else {
               const int v = ~link, first = v >> 3, count = (v & 7) + 1;
+              n_leaf += count;
               for (int k = 0; k < count; k++) {
                 const float4 g = sc.leaf_geo[first + k];
                 float Px, Py, Pz;
@@ -531,6 +535,11 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
             else
               done = true;
           }
+        }
+        if (VERIFY && st.walk) {
+          atomicAdd(st.walk + 0, 1ull);
+          atomicAdd(st.walk + 1, (unsigned long long)n_nodes);
+          atomicAdd(st.walk + 2, (unsigned long long)n_leaf);
         }
       }
     }

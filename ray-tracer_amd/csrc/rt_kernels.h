@@ -72,8 +72,11 @@ hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
                          const FrameDev &f, const BounceDev &bd,
                          int owned_tile_rows, bool beam,
                          unsigned long long *verify_stats, hipStream_t st);
+// verify_stats (device uint64[8] or null): [0..1] as launch_render, [2..4] rays /
+// node bounds / leaf spheres of nearest-hit walks, [5..7] the same for shadow walks.
 hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
-                         uint64_t *ray_count, int blocks, hipStream_t st);
+                         uint64_t *ray_count, unsigned long long *verify_stats,
+                         int blocks, hipStream_t st);
 hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
                           hipStream_t st);
 hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,

@@ -389,9 +389,9 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
 // ---------------------------------------------------------------------------
 // The grid is fixed; waves stride over the queue, whose length is read from
 // device memory (the host never waits for it).
-template <bool BEAM>
+template <bool BEAM, bool VERIFY>
 __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
-                                                uint64_t *ray_count) {
+                                                uint64_t *ray_count, ScreenStats st) {
   uint32_t n_in = *bd.in.count;
   if (n_in > bd.in.capacity)
     n_in = bd.in.capacity;
@@ -412,14 +412,17 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
     }
     const uint32_t tag = __float_as_uint(b.w);
     const uint32_t pixel = tag >> 6, depth = tag & 63u;
-    Hit h = trace<false, false, BM, false>(sc, live, a.x, a.y, a.z, b.x, b.y, b.z);
+    Hit h = trace<false, false, BM, VERIFY>(sc, live, a.x, a.y, a.z, b.x, b.y, b.z, 0.f,
+                                            0.f, 0.f, 0.f, st);
     if (live)
       n_rays++;
     const bool hit = live && h.kind != 0;
     uint32_t u0 = 0, u1 = 0, u2 = 0;
-    n_rays += shade_hits<false, true, BS, false>(sc, bd, hit, h, b.x, b.y, b.z, a.w, pixel,
-                                                 depth, u0, u1, u2,
-                                                 ScreenStats{nullptr, nullptr});
+    ScreenStats st2 = st;
+    if (st2.walk)
+      st2.walk += 3; // shadow-ray walks are counted apart from nearest-hit walks
+    n_rays += shade_hits<false, true, BS, VERIFY>(sc, bd, hit, h, b.x, b.y, b.z, a.w, pixel,
+                                                  depth, u0, u1, u2, st2);
   }
   add_ray_count(ray_count, n_rays);
 }
@@ -491,12 +494,15 @@ hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
   if (owned_tile_rows <= 0)
     return hipSuccess;
   dim3 grid((f.w + 31) / 32, owned_tile_rows);
-  ScreenStats ss{nullptr, nullptr};
+  ScreenStats ss{nullptr, nullptr, nullptr};
   const bool mats = bd.max_depth > 1;
   if (verify_stats) {
     ss.dropped_but_candidate = verify_stats;
     ss.kept = verify_stats + 1;
-    hipLaunchKernelGGL((k_render<true, true, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
+    if (mats)
+      hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
+    else
+      hipLaunchKernelGGL((k_render<true, true, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
   } else if (beam && mats) {
     hipLaunchKernelGGL((k_render<true, false, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
   } else if (beam) {
@@ -510,11 +516,22 @@ hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
 }
 
 hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
-                         uint64_t *ray_count, int blocks, hipStream_t st) {
-  if (beam)
-    hipLaunchKernelGGL((k_bounce<true>), dim3(blocks), dim3(256), 0, st, sc, bd, ray_count);
-  else
-    hipLaunchKernelGGL((k_bounce<false>), dim3(blocks), dim3(256), 0, st, sc, bd, ray_count);
+                         uint64_t *ray_count, unsigned long long *verify_stats,
+                         int blocks, hipStream_t st) {
+  ScreenStats ss{nullptr, nullptr, nullptr};
+  if (verify_stats) {
+    ss.dropped_but_candidate = verify_stats;
+    ss.kept = verify_stats + 1;
+    ss.walk = verify_stats + 2;
+    hipLaunchKernelGGL((k_bounce<true, true>), dim3(blocks), dim3(256), 0, st, sc, bd,
+                       ray_count, ss);
+  } else if (beam) {
+    hipLaunchKernelGGL((k_bounce<true, false>), dim3(blocks), dim3(256), 0, st, sc, bd,
+                       ray_count, ss);
+  } else {
+    hipLaunchKernelGGL((k_bounce<false, false>), dim3(blocks), dim3(256), 0, st, sc, bd,
+                       ray_count, ss);
+  }
   return hipGetLastError();
 }
 

@@ -251,11 +251,11 @@ def test_screen_never_drops_a_candidate(name, w, h):
     else:
         sc = golden_scenes.full_frame_scenes()[name]
     fb = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
-    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    stats = torch.zeros(8, dtype=torch.int64, device="cuda")
     with rtamd.DeviceScene(sc) as ds:
         ds.render_device(fb.data_ptr(), None, w, h, dev_selfcheck_stats=stats.data_ptr())
         torch.cuda.synchronize()
-    dropped_but_candidate, kept = [int(x) for x in stats.cpu()]
+    dropped_but_candidate, kept = [int(x) for x in stats.cpu()][:2]
     waves = ((w + 31) // 32 * 4) * ((h + 7) // 8)
     print(f"{name}: kept {kept} sphere tests over {waves} waves "
           f"({kept / max(1, waves):.1f} per wave, {sc.s_size} spheres)")
