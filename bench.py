@@ -21,6 +21,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "ray-tracer_amd", "python"))
 
 import rtamd  # noqa: E402
+from rt_shard import BandPlan  # noqa: E402
 
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32, FMA counted as 2 flop
 FLOP_PER_SPHERE_TEST = 25       # maths.cpp:126-133 up to the discriminant test
@@ -101,21 +102,13 @@ def main():
     n_tests_per_ray = FLOP_PER_SPHERE_TEST * sc.s_size + FLOP_PER_TRIANGLE_TEST * sc.t_size
 
     band_rows = args.band_rows
-    n_bands = (h + band_rows - 1) // band_rows
-    owned = list(range(rank, n_bands, world))
-    max_owned = (n_bands + world - 1) // world
-
-    fb = torch.zeros((n_bands * band_rows, w, 4), dtype=torch.uint8, device=dev)
+    plan = BandPlan(h, w, band_rows, rank, world)
+    fb = plan.alloc_frame(dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     ds = rtamd.DeviceScene(sc)
     rtamd.set_screen(args.screen == "on")
-    fb_bands = fb.view(n_bands, band_rows * w * 4)
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty((max_owned, band_rows * w * 4), dtype=torch.uint8, device=dev)
-                       for _ in range(world)]
-    send = torch.zeros((max_owned, band_rows * w * 4), dtype=torch.uint8, device=dev)
+    send, recv = plan.alloc_gather(dev)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     kernel_ms = []
@@ -128,13 +121,7 @@ def main():
                          dev_ray_count=cnt.data_ptr())
         if timed:
             ev1.record()
-        if world > 1:
-            send[:len(owned)].copy_(fb_bands[rank::world])
-            dist.gather(send, gather_list, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    k = len(range(r, n_bands, world))
-                    fb_bands[r::world].copy_(gather_list[r][:k])
+        plan.gather_to_rank0(fb, send, recv)
         if timed:
             ev1.synchronize()
             kernel_ms.append(ev0.elapsed_time(ev1))

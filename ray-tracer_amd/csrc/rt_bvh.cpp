@@ -50,6 +50,14 @@ struct Builder {
     return make_float4(cf[0], cf[1], cf[2], round_up(R * (1.0 + 1e-6)));
   }
 
+  static float near_bound(float4 s) {
+    double d = std::sqrt((double)s.x * s.x + (double)s.y * s.y + (double)s.z * s.z) - (double)s.w;
+    float f = (float)(d * (d > 0 ? 1.0 - 1e-6 : 1.0 + 1e-6));
+    if ((double)f > d)
+      f = std::nextafter(f, -INFINITY);
+    return f;
+  }
+
   // Returns the link for order[b, e) and its bounding sphere.
   int32_t build(int b, int e, float4 &sphere) {
     int axis;
@@ -77,7 +85,8 @@ struct Builder {
     N.s1 = s1;
     N.link0 = l0;
     N.link1 = l1;
-    N.pad0 = N.pad1 = 0;
+    N.near0 = near_bound(s0);
+    N.near1 = near_bound(s1);
     return me;
   }
 };
@@ -112,6 +121,7 @@ void bvh_build(const float *spheres, const float *radius, int n, BvhHost &out) {
     out.nodes[0].s1 = root;
     out.nodes[0].link0 = l;
     out.nodes[0].link1 = BVH_EMPTY;
+    out.nodes[0].near0 = out.nodes[0].near1 = -INFINITY;
   } else {
     out.nodes.pop_back();
     int32_t l = B.build(0, n, root);

@@ -19,7 +19,8 @@ namespace rt {
 struct BvhNode {
   float4 s0, s1; // centre.xyz, radius (covers every member sphere entirely)
   int32_t link0, link1;
-  int32_t pad0, pad1;
+  float near0, near1; // |centre| - radius rounded down: no point of the child is
+                      // closer to the world origin than this
 };
 constexpr int32_t BVH_EMPTY = 0x7fffffff;
 constexpr int BVH_LEAF_MAX = 4;

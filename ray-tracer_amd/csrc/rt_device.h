@@ -353,15 +353,32 @@ struct ScreenStats { // filled only by the verification build of the kernels
 // which exceeds the rounding of its five products and sums (and of using the
 // float a for |d|^2); Rtot is rounded outwards through its two coefficients.
 // NaN or inf anywhere answers yes.
-__device__ __forceinline__ bool bvh_touches(float4 s, float ox, float oy, float oz,
-                                            float dx, float dy, float dz, float a) {
+//
+// Two more ways out, both one-sided:
+//  - the node lies behind the ray origin: (C - o).d/|d| + R < -mu with
+//    mu = 2^-8 (|M| + R).  Then for every member sphere d.L > 0 and
+//    |L|^2 - r^2 > 0 by margins thousands of times their rounding, so
+//    maths.cpp:138-152 computes two negative roots and reports no hit;
+//  - every point of the node is farther from the world origin than `bound`
+//    (the best |P| so far): near - mu > bound.  A reported P is within mu of the
+//    sphere it belongs to even when the roots are ill-conditioned (the
+//    discriminant carries an absolute error <= 17u (2|d||L|)^2, i.e. <= 1e-3 |L|
+//    on the roots), so such a node cannot supply a nearer hit.  Ties are kept:
+//    the comparison is strict.
+__device__ __forceinline__ bool bvh_touches(float4 s, float near, float ox, float oy,
+                                            float oz, float dx, float dy, float dz,
+                                            float a, float da, float bound) {
   float Mx = s.x - ox, My = s.y - oy, Mz = s.z - oz;
   float m2 = fmaf(Mz, Mz, fmaf(My, My, Mx * Mx));
   float md = fmaf(dz, Mz, fmaf(dy, My, dx * Mx));
-  float Rtot = fmaf(s.w, 1.002f, __builtin_amdgcn_sqrtf(m2) * 0.00196f);
+  float mlen = __builtin_amdgcn_sqrtf(m2);
+  float Rtot = fmaf(s.w, 1.002f, mlen * 0.00196f);
   float lhs = fmaf(-md, md, (a * m2) * 0.99999809265136719f);
   float rhs = (a * Rtot) * (Rtot * 1.000001f);
-  return !(lhs > rhs);
+  float mu = fmaf(mlen, 0.0040f, s.w * 0.0040f); // > 2^-8 (|M| + R)
+  bool behind = fmaf(da, s.w + mu, md) < 0.f;
+  bool far = (near - mu) > bound;
+  return !(lhs > rhs) && !behind && !far;
 }
 
 template <bool FROM_EYE, bool ANY_HIT, int BEAM, bool VERIFY = false>
@@ -487,15 +504,24 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
         int node = 0;
         bool done = false;
         unsigned n_nodes = 0, n_leaf = 0;
+        const float da = sqrtf(a) * 1.000244140625f; // >= |d|
+        // a sphere can only win against the nearest triangle by being strictly
+        // nearer (renderer.cpp:181)
+        float bound = ANY_HIT ? RT_INF : len_t;
         while (!done) {
           const BvhNode N = sc.bvh[node];
           int next = -1;
           n_nodes += 2;
+          // the child nearer to the world origin first: it tightens `bound`
+          const bool swap = N.near1 < N.near0;
 #pragma unroll
-          for (int c = 0; c < 2; c++) {
+          for (int cc = 0; cc < 2; cc++) {
+            const bool c = (cc != 0) != swap;
             const float4 s = c ? N.s1 : N.s0;
+            const float near = c ? N.near1 : N.near0;
             const int32_t link = c ? N.link1 : N.link0;
-            if (link == BVH_EMPTY || !bvh_touches(s, ox, oy, oz, dx, dy, dz, a))
+            if (link == BVH_EMPTY ||
+                !bvh_touches(s, near, ox, oy, oz, dx, dy, dz, a, da, bound))
               continue;
             if (link >= 0) {
               if (next < 0)
@@ -522,6 +548,8 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                     sPz = Pz;
                     if (ANY_HIT)
                       done = true;
+                    else
+                      bound = fminf(bound, len);
                   }
                 }
               }
