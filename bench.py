@@ -78,8 +78,9 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--screen", choices=["on", "off"], default="on",
-                    help="beam screen (default) or the plain every-ray-every-sphere loop")
+    ap.add_argument("--screen", choices=["auto", "off", "beam", "bvh"], default="auto",
+                    help="work avoidance mode (rt_set_screen); off = plain every-ray-"
+                         "every-sphere loop")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +108,7 @@ def main():
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     ds = rtamd.DeviceScene(sc)
-    rtamd.set_screen(args.screen == "on")
+    rtamd.set_screen(args.screen)
     send, recv = plan.alloc_gather(dev)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
@@ -180,7 +181,7 @@ def main():
                                  "frac can exceed 1 (plain_loop = screen off)"},
         }
         out["config"]["screen"] = args.screen
-        if world == 1 and args.screen == "on":
+        if world == 1 and args.screen != "off":
             # the same frame with the screen off: the brute-force formulation the
             # FP32 roofline is defined on (every ray against every primitive)
             rtamd.set_screen(False)
@@ -189,7 +190,7 @@ def main():
             kernel_ms.clear()
             for _ in range(2):
                 step(True)
-            rtamd.set_screen(True)
+            rtamd.set_screen(args.screen)
             bf_ms = float(np.mean(kernel_ms))
             bf = my_rays_per_launch * n_tests_per_ray / (bf_ms * 1e-3) / 1e12
             out["roofline"]["plain_loop"] = {

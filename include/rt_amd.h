@@ -139,15 +139,22 @@ int rt_render_device(rt_scene *scene, const camera *cam, const rt_frame *frame,
  * gpu_render/gpu_render_ids check it themselves and return RT_ERR_CAPACITY).  */
 int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
 
-/* ---- the beam screen (no counterpart in the reference) ---------------------
- * By default each wave first screens the spheres, 64 at a time, against a cone
- * that contains all of its rays, and runs the reference's per-ray arithmetic
- * only on spheres the cone can touch.  The screen is conservative by
- * construction, so images, ids and ray counts are identical with it on or off;
- * it only removes work.  rt_set_screen(0) selects the plain loop that tests
- * every ray against every sphere (used to measure the brute-force roofline).
+/* ---- work avoidance (no counterpart in the reference) ----------------------
+ * The reference tests every ray against every primitive (renderer.cpp:156-177).
+ * The library gets the same answers with far fewer tests, in two ways:
+ *   - beam screen: a wave's rays that share an apex (primary rays: the eye;
+ *     shadow rays: the light) are bounded by a cone, the spheres are screened
+ *     64 at a time (one per lane) against that cone, and the reference's per-ray
+ *     arithmetic runs only on spheres the cone can touch;
+ *   - sphere hierarchy: a bounding-sphere tree built at rt_scene_create; each
+ *     lane walks it for its own ray (bounce rays, bulk queries, and by default
+ *     also primary and shadow rays).
+ * Both are conservative by construction, so images, ids and ray counts are
+ * identical in every mode.  mode: 0 = plain loop, every ray against every
+ * sphere (used to measure the brute-force roofline); 1 = automatic (default);
+ * 2 = beam screen for primary/shadow rays; 3 = hierarchy for all rays.
  * Process-wide; not thread-safe against concurrent renders.                   */
-void rt_set_screen(int enabled);
+void rt_set_screen(int mode);
 int rt_get_screen(void);
 
 /* As rt_render_device, with a slow self-checking build of the kernel that

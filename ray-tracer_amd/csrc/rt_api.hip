@@ -391,8 +391,15 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
     bd.out = queue_for_level(S, 2);
   }
   const rt::SceneDev sd = S->dev();
+  // 0 plain loop, 1 automatic (hierarchy when the scene has one, else the beam
+  // screen), 2 beam screen, 3 hierarchy
+  int accel = RT_BEAM_NONE;
+  if (g_screen == 2 || ((g_screen == 1 || g_screen == 3) && !S->has_bvh))
+    accel = RT_BEAM_APEX;
+  else if (g_screen == 1 || g_screen == 3)
+    accel = RT_ACCEL_BVH;
   HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, owned_tile_rows,
-                            g_screen != 0, (unsigned long long *)dev_verify, st));
+                            accel, (unsigned long long *)dev_verify, st));
   if (bounces) {
     for (int level = 2; level <= fr->max_depth; level++) {
       bd.in = queue_for_level(S, level);

@@ -64,13 +64,14 @@ struct CheckArgs {
 
 hipError_t launch_prep_scene(const PrepArgs &a, hipStream_t st);
 hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st);
-// beam: screen spheres per wave before the per-ray tests (same results, far
-// less work).  verify_stats: device uint64[2] {spheres dropped although a ray's
+// accel: RT_BEAM_NONE (plain loop), RT_BEAM_APEX (screen spheres per wave
+// before the per-ray tests) or RT_ACCEL_BVH (every lane walks the sphere
+// hierarchy); same results, different amounts of work.  verify_stats: device uint64[2] {spheres dropped although a ray's
 // discriminant test passes (must stay 0), spheres kept}; selects a slow
 // self-checking build of the kernel.
 hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
                          const FrameDev &f, const BounceDev &bd,
-                         int owned_tile_rows, bool beam,
+                         int owned_tile_rows, int accel,
                          unsigned long long *verify_stats, hipStream_t st);
 // verify_stats (device uint64[8] or null): [0..1] as launch_render, [2..4] rays /
 // node bounds / leaf spheres of nearest-hit walks, [5..7] the same for shadow walks.

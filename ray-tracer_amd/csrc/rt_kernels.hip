@@ -338,7 +338,7 @@ __device__ __forceinline__ void add_ray_count(uint64_t *counter, uint32_t n) {
 // block's pixel writes cover 128 contiguous bytes per row.  blockIdx.y counts
 // the tile rows this call owns; bands of band_rows rows are dealt round-robin
 // over band_count callers (row sharding, renderer.cpp:27-28).
-template <bool BEAM, bool VERIFY, bool MATERIALS>
+template <int ACCEL, bool VERIFY, bool MATERIALS>
 __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
                                                 FrameDev f, BounceDev bd,
                                                 ScreenStats st) {
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
   float dx = px - cam.ox, dy = py - cam.oy, dz = cam.plane_z - cam.oz;
   normalize3(dx, dy, dz);
 
-  constexpr int BM = BEAM ? RT_BEAM_APEX : RT_BEAM_NONE;
+  constexpr int BM = ACCEL;
   Hit h = trace<true, false, BM, VERIFY>(sc, inside, cam.ox, cam.oy, cam.oz, dx,
                                          dy, dz, cam.ox, cam.oy, cam.oz, 0.f, st);
 
@@ -489,29 +489,39 @@ hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st) {
 
 hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
                          const FrameDev &f, const BounceDev &bd,
-                         int owned_tile_rows, bool beam,
+                         int owned_tile_rows, int accel,
                          unsigned long long *verify_stats, hipStream_t st) {
   if (owned_tile_rows <= 0)
     return hipSuccess;
   dim3 grid((f.w + 31) / 32, owned_tile_rows);
   ScreenStats ss{nullptr, nullptr, nullptr};
   const bool mats = bd.max_depth > 1;
+#define RT_LAUNCH(A, V, M)                                                               \
+  hipLaunchKernelGGL((k_render<A, V, M>), grid, dim3(256), 0, st, sc, cam, f, bd, ss)
   if (verify_stats) {
     ss.dropped_but_candidate = verify_stats;
     ss.kept = verify_stats + 1;
     if (mats)
-      hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
+      RT_LAUNCH(RT_BEAM_APEX, true, true);
     else
-      hipLaunchKernelGGL((k_render<true, true, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
-  } else if (beam && mats) {
-    hipLaunchKernelGGL((k_render<true, false, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
-  } else if (beam) {
-    hipLaunchKernelGGL((k_render<true, false, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
-  } else if (mats) {
-    hipLaunchKernelGGL((k_render<false, false, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
+      RT_LAUNCH(RT_BEAM_APEX, true, false);
+  } else if (accel == RT_BEAM_APEX) {
+    if (mats)
+      RT_LAUNCH(RT_BEAM_APEX, false, true);
+    else
+      RT_LAUNCH(RT_BEAM_APEX, false, false);
+  } else if (accel == RT_ACCEL_BVH && sc.bvh) {
+    if (mats)
+      RT_LAUNCH(RT_ACCEL_BVH, false, true);
+    else
+      RT_LAUNCH(RT_ACCEL_BVH, false, false);
   } else {
-    hipLaunchKernelGGL((k_render<false, false, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);
+    if (mats)
+      RT_LAUNCH(RT_BEAM_NONE, false, true);
+    else
+      RT_LAUNCH(RT_BEAM_NONE, false, false);
   }
+#undef RT_LAUNCH
   return hipGetLastError();
 }
 

@@ -174,9 +174,15 @@ def _check(code: int):
         raise RtError(code, lib().rt_last_error().decode())
 
 
-def set_screen(enabled: bool):
-    """rt_set_screen: beam screen on (default) or the plain every-ray-every-sphere loop."""
-    lib().rt_set_screen(1 if enabled else 0)
+SCREEN_MODES = {"off": 0, "auto": 1, "beam": 2, "bvh": 3}
+
+
+def set_screen(mode):
+    """rt_set_screen: "off" (plain every-ray-every-sphere loop), "auto" (default),
+    "beam" or "bvh"; True/False mean "auto"/"off"."""
+    if isinstance(mode, bool):
+        mode = "auto" if mode else "off"
+    lib().rt_set_screen(SCREEN_MODES[mode])
 
 
 def render(scene: Scene, w: int, h: int, max_depth: int = 1,

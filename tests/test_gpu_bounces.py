@@ -108,13 +108,16 @@ def test_10k_grid_4k_depth8_row_sample(oracle):
 
 def test_screen_off_gives_the_same_bounces(oracle):
     sc = material_scene(54, n_spheres=120)
-    try:
-        rtamd.set_screen(False)
-        fb0, _, n0 = rtamd.render(sc, 320, 200, max_depth=6)
-    finally:
-        rtamd.set_screen(True)
-    fb1, _, n1 = rtamd.render(sc, 320, 200, max_depth=6)
-    assert np.array_equal(fb0, fb1) and n0 == n1
+    out = {}
+    for mode in ("off", "beam", "bvh", "auto"):
+        try:
+            rtamd.set_screen(mode)
+            out[mode] = rtamd.render(sc, 320, 200, max_depth=6)
+        finally:
+            rtamd.set_screen("auto")
+    fo, _, no = oracle.render(sc, 320, 200, max_depth=6, want_ids=False)
+    for mode, (fb, _, n) in out.items():
+        assert np.array_equal(fb, fo) and n == no, mode
 
 
 def test_invalid_materials_rejected():

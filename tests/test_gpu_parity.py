@@ -220,19 +220,30 @@ def test_reference_signature_shim(golden, oracle):
             assert idx.value == -5  # untouched on a miss
 
 
-def test_plain_loop_equals_screened(oracle):
-    """rt_set_screen(0): every ray against every sphere.  Same bytes."""
+@pytest.mark.parametrize("mode", ["off", "beam", "bvh", "auto"])
+def test_every_mode_gives_the_same_bytes(oracle, mode):
+    """rt_set_screen: plain loop, beam screen, sphere hierarchy.  Same bytes."""
     sc = golden_scenes.mixed_scene(seed=12, n_spheres=200)
     try:
-        rtamd.set_screen(False)
-        fb0, ids0, n0 = rtamd.render(sc, 640, 400)
+        rtamd.set_screen(mode)
+        fb, ids, n = rtamd.render(sc, 640, 400)
     finally:
-        rtamd.set_screen(True)
-    fb1, ids1, n1 = rtamd.render(sc, 640, 400)
+        rtamd.set_screen("auto")
     fo, io, no = oracle.render(sc, 640, 400)
-    assert_frame_parity(fb0, ids0, fo, io, "plain loop")
-    assert_frame_parity(fb1, ids1, fo, io, "screened")
-    assert n0 == n1 == no
+    assert_frame_parity(fb, ids, fo, io, mode)
+    assert n == no
+
+
+@pytest.mark.parametrize("mode", ["beam", "bvh"])
+def test_reference_golden_in_each_mode(golden, mode):
+    sc = golden_scenes.full_frame_scenes()["g30"]
+    try:
+        rtamd.set_screen(mode)
+        fb, ids, _ = rtamd.render(sc, W, H)
+    finally:
+        rtamd.set_screen("auto")
+    assert np.array_equal(row_crc(ids), golden["g30_idcrc"])
+    assert np.array_equal(row_crc(fb), golden["g30_fbcrc"])
 
 
 @pytest.mark.parametrize("name,w,h", [("shipped", 2560, 1440), ("mixed", 1280, 720),
@@ -255,6 +266,7 @@ def test_screen_never_drops_a_candidate(name, w, h):
     with rtamd.DeviceScene(sc) as ds:
         ds.render_device(fb.data_ptr(), None, w, h, dev_selfcheck_stats=stats.data_ptr())
         torch.cuda.synchronize()
+    # the self-checking build always runs the beam screen
     dropped_but_candidate, kept = [int(x) for x in stats.cpu()][:2]
     waves = ((w + 31) // 32 * 4) * ((h + 7) // 8)
     print(f"{name}: kept {kept} sphere tests over {waves} waves "
