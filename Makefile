@@ -20,7 +20,19 @@ all: lib oracle
 
 SHIM     := ray-tracer_amd/host/librt_shim.so
 
-lib: $(LIB) $(SHIM)
+HOSTLIB  := ray-tracer_amd/host/librt_host.so
+DRIVER   := ray-tracer_amd/host/raytracer_amd
+
+lib: $(LIB) $(SHIM) $(HOSTLIB) $(DRIVER)
+
+# scene-file reader, grid generator, PPM writer (no GPU code)
+$(HOSTLIB): ray-tracer_amd/host/scene_io.cpp include/rt_host.h
+	g++ -std=c++11 -O2 -ffp-contract=off -fPIC -shared -o $@ ray-tracer_amd/host/scene_io.cpp
+
+# headless driver with the reference's command line
+$(DRIVER): ray-tracer_amd/host/rt_main.cpp $(HOSTLIB) $(LIB) include/rt_amd.h include/rt_host.h
+	g++ -std=c++11 -O2 -o $@ ray-tracer_amd/host/rt_main.cpp -Lray-tracer_amd/host -lrt_host \
+	    -L$(CSRC) -lrt_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
 
 # The reference's render()/check_intersection() signatures on top of $(LIB)
 $(SHIM): ray-tracer_amd/host/render_shim.cpp include/rt_amd.h $(LIB)
@@ -39,7 +51,7 @@ isa: $(SRCS) $(HDRS)
 	    -Rpass-analysis=kernel-resource-usage
 
 clean:
-	rm -f $(LIB) $(SHIM)
+	rm -f $(LIB) $(SHIM) $(HOSTLIB) $(DRIVER)
 	rm -rf build
 	$(MAKE) -C oracle clean
 
