@@ -75,8 +75,14 @@ struct rt_scene {
   float eye[3] = {0, 0, 0};
   // bounce machinery, allocated on the first max_depth > 1 render
   DevBuf<float4> queue[2];
-  DevBuf<uint32_t> counts; // [0..63] per-level queue lengths, [64] overflow flag
+  // control words.  A "row" is one counter per queue segment (QUEUE_SEGMENTS x
+  // CTL_WORDS uint32).  Per level: rows {queue length, walk cursor, hit count} then
+  // per light {shadow items, shadow cursor}; the very last word is the overflow flag
+  DevBuf<uint32_t> counts;
+  int ctl_rows = 0; // rows per level
   DevBuf<uint32_t> extra;  // 3 per pixel
+  DevBuf<float4> hit_rec, shadow_items;
+  DevBuf<uint32_t> hit_ray;
   size_t queue_capacity = 0, extra_pixels = 0;
 
   rt::SceneDev dev() const {
@@ -247,18 +253,25 @@ int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
 constexpr int kMaxDepth = 63;       // depth is stored in 6 bits of the ray tag
 constexpr int kBounceBlocks = 2048; // 8 blocks of 256 lanes per CU
 
+constexpr int kLevels = 66; // levels 0..65 (depth <= 63, +1 for the last spawn target)
+constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
+
 int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels) {
   size_t want = 4 * owned_pixels + 65536;
-  if (want > 0xfffffff0ull)
-    want = 0xfffffff0ull;
+  if (want > 0x0ffffff0ull)
+    want = 0x0ffffff0ull;
+  want = (want + rt::QUEUE_SEGMENTS - 1) / rt::QUEUE_SEGMENTS * rt::QUEUE_SEGMENTS;
   if (S->queue_capacity < want) {
     for (int q = 0; q < 2; q++)
       HIP_TRY(S->queue[q].alloc(2 * want));
+    HIP_TRY(S->hit_rec.alloc(want));
+    HIP_TRY(S->hit_ray.alloc(want));
+    HIP_TRY(S->shadow_items.alloc(2 * want));
     S->queue_capacity = want;
   }
   if (!S->counts.p) {
-    HIP_TRY(S->counts.alloc(65));
-    HIP_TRY(hipMemset(S->counts.p, 0, 65 * sizeof(uint32_t)));
+    S->ctl_rows = 3 + 2 * (S->l_size > 0 ? S->l_size : 1);
+    HIP_TRY(S->counts.alloc((size_t)kLevels * S->ctl_rows * kRowWords + 1));
   }
   if (S->extra_pixels < frame_pixels) {
     HIP_TRY(S->extra.alloc(3 * frame_pixels));
@@ -268,12 +281,19 @@ int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels)
   return RT_OK;
 }
 
+uint32_t *ctl(rt_scene *S, int level, int row) {
+  return S->counts.p + ((size_t)level * S->ctl_rows + row) * kRowWords;
+}
+uint32_t *overflow_flag(rt_scene *S) {
+  return S->counts.p + (size_t)kLevels * S->ctl_rows * kRowWords;
+}
+
 rt::RayQueue queue_for_level(rt_scene *S, int level) {
   rt::RayQueue q;
   q.items = S->queue[level & 1].p;
-  q.count = S->counts.p + level;
-  q.capacity = (uint32_t)S->queue_capacity;
-  q.overflow = S->counts.p + 64;
+  q.count = ctl(S, level, 0);
+  q.seg_capacity = (uint32_t)(S->queue_capacity / rt::QUEUE_SEGMENTS);
+  q.overflow = overflow_flag(S);
   return q;
 }
 
@@ -385,7 +405,11 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
                                (size_t)owned_tile_rows * 8 * fr->w);
     if (rc)
       return rc;
-    HIP_TRY(hipMemsetAsync(S->counts.p, 0, 65 * sizeof(uint32_t), st));
+    // only the levels this frame can reach, and the overflow flag
+    HIP_TRY(hipMemsetAsync(S->counts.p, 0,
+                           (size_t)(fr->max_depth + 2) * S->ctl_rows * kRowWords * sizeof(uint32_t),
+                           st));
+    HIP_TRY(hipMemsetAsync(overflow_flag(S), 0, sizeof(uint32_t), st));
     bd.max_depth = fr->max_depth;
     bd.extra = S->extra.p;
     bd.out = queue_for_level(S, 2);
@@ -401,11 +425,56 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
   HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, owned_tile_rows,
                             accel, (unsigned long long *)dev_verify, st));
   if (bounces) {
+    // With a sphere hierarchy each level runs as walk / shade / shadow-walk
+    // launches with dynamic ray fetch (rt_walk.h); otherwise, or in the
+    // self-checking build, as one k_bounce launch per level.
+    const bool stream_levels = sd.bvh != nullptr && !dev_verify;
     for (int level = 2; level <= fr->max_depth; level++) {
       bd.in = queue_for_level(S, level);
       bd.out = queue_for_level(S, level + 1);
-      HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count,
-                                (unsigned long long *)dev_verify, kBounceBlocks, st));
+      if (!stream_levels) {
+        HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count,
+                                  (unsigned long long *)dev_verify, kBounceBlocks, st));
+        continue;
+      }
+      rt::HitList hl;
+      hl.rec = S->hit_rec.p;
+      hl.ray = S->hit_ray.p;
+      hl.count = ctl(S, level, 2);
+      hl.seg_capacity = bd.in.seg_capacity;
+      rt::WalkArgs wa;
+      memset(&wa, 0, sizeof wa);
+      wa.in = bd.in;
+      wa.cursor = ctl(S, level, 1);
+      wa.hits = hl;
+      wa.extra = S->extra.p;
+      wa.ray_count = dev_ray_count;
+      HIP_TRY(rt::launch_walk(sd, wa, false, kBounceBlocks, st));
+      rt::ShadeArgs sa;
+      memset(&sa, 0, sizeof sa);
+      sa.rays = bd.in;
+      sa.hits = hl;
+      sa.max_depth = fr->max_depth;
+      sa.next = bd.out;
+      const int n_passes = S->l_size > 0 ? S->l_size : 1;
+      for (int l = 0; l < n_passes; l++) {
+        sa.light = S->l_size > 0 ? l : -1;
+        sa.spawn = l == 0;
+        sa.shadow.items = S->shadow_items.p;
+        sa.shadow.count = ctl(S, level, 3 + 2 * l);
+        sa.shadow.seg_capacity = bd.in.seg_capacity;
+        sa.shadow.overflow = overflow_flag(S);
+        HIP_TRY(rt::launch_shade(sd, sa, kBounceBlocks, st));
+        if (S->l_size > 0) {
+          rt::WalkArgs ws;
+          memset(&ws, 0, sizeof ws);
+          ws.in = sa.shadow;
+          ws.cursor = ctl(S, level, 4 + 2 * l);
+          ws.extra = S->extra.p;
+          ws.ray_count = dev_ray_count;
+          HIP_TRY(rt::launch_walk(sd, ws, true, kBounceBlocks, st));
+        }
+      }
     }
     HIP_TRY(rt::launch_compose(fr->dev_fb, S->extra.p, (size_t)fr->w * fr->h, st));
   }
@@ -432,7 +501,7 @@ int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {
     return RT_OK;
   uint32_t flag = 0;
   HIP_TRY(hipSetDevice(S->device));
-  HIP_TRY(hipMemcpy(&flag, S->counts.p + 64, sizeof flag, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&flag, overflow_flag(S), sizeof flag, hipMemcpyDeviceToHost));
   *overflowed = flag != 0;
   return RT_OK;
 }

@@ -39,11 +39,28 @@ struct FrameDev {
 
 // Bounce-ray queue in HBM: two float4 per ray,
 //   (origin.xyz, weight) and (dir.xyz, bits of (pixel << 6 | depth)).
+// The queue is cut into n_seg equal segments, each with its own length counter
+// 256 bytes from the next: every wave of a block appends to (and later consumes
+// from) segment  block % n_seg.  One shared counter hands out only ~90 M slots/s
+// on this chip (returning atomics on one address serialise at ~11 ns); spread
+// over 64+ addresses the same atomics run at > 4 G/s (tools/atomic_rate.hip).
+constexpr int QUEUE_SEGMENTS = 128;
+constexpr int CTL_WORDS = 64; // uint32 words between two segments' counters
+
 struct RayQueue {
-  float4 *items;
-  uint32_t *count;    // rays appended (may exceed capacity: the excess is dropped)
-  uint32_t capacity;
+  float4 *items;      // segment s holds items [s * seg_capacity, (s+1) * seg_capacity)
+  uint32_t *count;    // count[s * CTL_WORDS]: rays appended to segment s (may exceed
+                      // seg_capacity: the excess is dropped and `overflow` is set)
+  uint32_t seg_capacity;
   uint32_t *overflow; // set to 1 when a ray had to be dropped
+};
+
+// Compact list of nearest hits, segmented like the queue the rays came from.
+struct HitList {
+  float4 *rec;        // P.xyz, bits of (kind << 28 | index)
+  uint32_t *ray;      // global queue slot of the ray that hit
+  uint32_t *count;    // count[s * CTL_WORDS]
+  uint32_t seg_capacity;
 };
 
 struct BounceDev {
@@ -51,6 +68,26 @@ struct BounceDev {
   RayQueue out;    // rays spawned for the next level
   uint32_t *extra; // 3 x uint32 per pixel: integer light of bounce hits
   int max_depth;   // 1 = no bounces (all other fields may be null)
+};
+
+// Bounce levels as separate launches (rt_walk.h).
+struct WalkArgs {
+  RayQueue in;        // items to walk: (origin, tagA bits), (direction, tagB bits)
+  uint32_t *cursor;   // cursor[s * CTL_WORDS]: next item of segment s to hand out
+  HitList hits;       // nearest-hit walks: where hits go
+  uint32_t *extra;    // shadow walks: tagA = pixel, tagB = packed integer light,
+                      // added to the pixel if unoccluded
+  uint64_t *ray_count;
+};
+
+struct ShadeArgs {
+  RayQueue rays;     // the level's rays (read through HitList::ray)
+  HitList hits;
+  int light;         // light to evaluate in this launch, or -1
+  int spawn;         // also queue the next level's rays
+  int max_depth;
+  RayQueue shadow;   // shadow-ray items for `light`
+  RayQueue next;     // next level's rays
 };
 
 struct CheckArgs {
@@ -78,6 +115,9 @@ hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
 hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
                          uint64_t *ray_count, unsigned long long *verify_stats,
                          int blocks, hipStream_t st);
+hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, int blocks,
+                       hipStream_t st);
+hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st);
 hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
                           hipStream_t st);
 hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,

@@ -206,30 +206,48 @@ __device__ __forceinline__ void refract3(float dx, float dy, float dz, float nx,
   normalize3(rx, ry, rz);
 }
 
-// Wave-aggregated append: one atomic per wave, lanes write consecutive slots.
+// The segment a block appends to and consumes from.
+__device__ __forceinline__ uint32_t my_segment() {
+  return (blockIdx.y * gridDim.x + blockIdx.x) % QUEUE_SEGMENTS;
+}
+
+// Wave-aggregated append: one atomic per wave, lanes write consecutive slots of
+// the block's segment.  Lanes that find the segment full move on to the next
+// one; only when every segment is full is the ray dropped and `overflow` set.
+__device__ __forceinline__ void queue_push_raw(const RayQueue &q, bool want, float4 a,
+                                               float4 b) {
+  const int lane = threadIdx.x & 63;
+  uint32_t seg = my_segment();
+  for (int attempt = 0; attempt < QUEUE_SEGMENTS; attempt++) {
+    const unsigned long long m = __ballot(want);
+    if (!m)
+      return;
+    const int leader = __builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(q.count + seg * CTL_WORDS, (uint32_t)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (want) {
+      const uint32_t slot = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (slot < q.seg_capacity) {
+        const size_t g = (size_t)seg * q.seg_capacity + slot;
+        q.items[2 * g] = a;
+        q.items[2 * g + 1] = b;
+        want = false;
+      }
+    }
+    seg = (seg + 1) % QUEUE_SEGMENTS;
+  }
+  if (want)
+    *q.overflow = 1u;
+}
+
 __device__ __forceinline__ void queue_push(const RayQueue &q, bool want, float ox,
                                            float oy, float oz, float dx, float dy,
                                            float dz, float w, uint32_t pixel,
                                            uint32_t depth) {
-  const unsigned long long m = __ballot(want);
-  if (!m)
-    return;
-  const int lane = threadIdx.x & 63;
-  const int leader = __builtin_ctzll(m);
-  uint32_t base = 0;
-  if (lane == leader)
-    base = atomicAdd(q.count, (uint32_t)__builtin_popcountll(m));
-  base = __builtin_amdgcn_readlane(base, leader);
-  if (want) {
-    const uint32_t slot = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-    if (slot < q.capacity) {
-      q.items[2 * (size_t)slot] = make_float4(ox, oy, oz, w);
-      q.items[2 * (size_t)slot + 1] =
-          make_float4(dx, dy, dz, __uint_as_float((pixel << 6) | depth));
-    } else {
-      *q.overflow = 1u;
-    }
-  }
+  queue_push_raw(q, want, make_float4(ox, oy, oz, w),
+                 make_float4(dx, dy, dz, __uint_as_float((pixel << 6) | depth)));
 }
 
 // Shade the hits of one wave (renderer.cpp:62-128) and queue their bounces.
@@ -392,11 +410,15 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
 template <bool BEAM, bool VERIFY>
 __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
                                                 uint64_t *ray_count, ScreenStats st) {
-  uint32_t n_in = *bd.in.count;
-  if (n_in > bd.in.capacity)
-    n_in = bd.in.capacity;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+  // this block works on segment (block % n_seg) together with the other blocks
+  // of the same residue
+  const uint32_t seg = my_segment();
+  uint32_t n_in = bd.in.count[seg * CTL_WORDS];
+  if (n_in > bd.in.seg_capacity)
+    n_in = bd.in.seg_capacity;
+  const uint32_t sib = gridDim.x / QUEUE_SEGMENTS; // blocks per segment (grid is a multiple)
+  const uint32_t stride = sib * blockDim.x;
+  const uint32_t first = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + (threadIdx.x & ~63u);
   // Bounce rays of one wave share neither an origin nor a direction: every
   // lane walks the sphere hierarchy for its own ray, shadow rays included.
   constexpr int BM = BEAM ? RT_ACCEL_BVH : RT_BEAM_NONE;
@@ -407,8 +429,9 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
     const bool live = r < n_in;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (live) {
-      a = bd.in.items[2 * (size_t)r];
-      b = bd.in.items[2 * (size_t)r + 1];
+      const size_t g = (size_t)seg * bd.in.seg_capacity + r;
+      a = bd.in.items[2 * g];
+      b = bd.in.items[2 * g + 1];
     }
     const uint32_t tag = __float_as_uint(b.w);
     const uint32_t pixel = tag >> 6, depth = tag & 63u;
@@ -446,6 +469,10 @@ __global__ void k_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels) {
   extra[3 * p + 1] = 0;
   extra[3 * p + 2] = 0;
 }
+
+} // namespace rt
+#include "rt_walk.h"
+namespace rt {
 
 // ---------------------------------------------------------------------------
 // k_check — bulk check_intersection (renderer.hpp:21-23)
@@ -542,6 +569,20 @@ hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
     hipLaunchKernelGGL((k_bounce<false, false>), dim3(blocks), dim3(256), 0, st, sc, bd,
                        ray_count, ss);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, int blocks,
+                       hipStream_t st) {
+  if (any_hit)
+    hipLaunchKernelGGL((k_walk<true>), dim3(blocks), dim3(256), 0, st, sc, w);
+  else
+    hipLaunchKernelGGL((k_walk<false>), dim3(blocks), dim3(256), 0, st, sc, w);
+  return hipGetLastError();
+}
+
+hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, st, sc, s);
   return hipGetLastError();
 }
 
