@@ -82,7 +82,7 @@ struct rt_scene {
   int ctl_rows = 0; // rows per level
   DevBuf<uint32_t> extra;  // 3 per pixel
   DevBuf<float4> hit_rec, shadow_items;
-  DevBuf<uint32_t> hit_ray;
+  DevBuf<int32_t> hit_idx;
   size_t queue_capacity = 0, extra_pixels = 0;
 
   rt::SceneDev dev() const {
@@ -253,6 +253,7 @@ int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
 constexpr int kMaxDepth = 63;       // depth is stored in 6 bits of the ray tag
 constexpr int kBounceBlocks = 2048; // 8 blocks of 256 lanes per CU
 
+constexpr int kLightGroup = 4; // lights whose shadow rays share one pass
 constexpr int kLevels = 66; // levels 0..65 (depth <= 63, +1 for the last spawn target)
 constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
 
@@ -265,12 +266,12 @@ int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels)
     for (int q = 0; q < 2; q++)
       HIP_TRY(S->queue[q].alloc(2 * want));
     HIP_TRY(S->hit_rec.alloc(want));
-    HIP_TRY(S->hit_ray.alloc(want));
-    HIP_TRY(S->shadow_items.alloc(2 * want));
+    HIP_TRY(S->hit_idx.alloc(want));
+    HIP_TRY(S->shadow_items.alloc(2 * want * kLightGroup));
     S->queue_capacity = want;
   }
   if (!S->counts.p) {
-    S->ctl_rows = 3 + 2 * (S->l_size > 0 ? S->l_size : 1);
+    S->ctl_rows = 2 + 2 * ((S->l_size + kLightGroup - 1) / kLightGroup + 1);
     HIP_TRY(S->counts.alloc((size_t)kLevels * S->ctl_rows * kRowWords + 1));
   }
   if (S->extra_pixels < frame_pixels) {
@@ -439,9 +440,7 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
       }
       rt::HitList hl;
       hl.rec = S->hit_rec.p;
-      hl.ray = S->hit_ray.p;
-      hl.count = ctl(S, level, 2);
-      hl.seg_capacity = bd.in.seg_capacity;
+      hl.idx = S->hit_idx.p;
       rt::WalkArgs wa;
       memset(&wa, 0, sizeof wa);
       wa.in = bd.in;
@@ -456,20 +455,22 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
       sa.hits = hl;
       sa.max_depth = fr->max_depth;
       sa.next = bd.out;
-      const int n_passes = S->l_size > 0 ? S->l_size : 1;
-      for (int l = 0; l < n_passes; l++) {
-        sa.light = S->l_size > 0 ? l : -1;
-        sa.spawn = l == 0;
+      sa.ray_count = dev_ray_count;
+      const int n_groups = S->l_size > 0 ? (S->l_size + kLightGroup - 1) / kLightGroup : 1;
+      for (int g = 0; g < n_groups; g++) {
+        sa.light_begin = g * kLightGroup;
+        sa.light_end = S->l_size < (g + 1) * kLightGroup ? S->l_size : (g + 1) * kLightGroup;
+        sa.spawn = g == 0;
         sa.shadow.items = S->shadow_items.p;
-        sa.shadow.count = ctl(S, level, 3 + 2 * l);
-        sa.shadow.seg_capacity = bd.in.seg_capacity;
+        sa.shadow.count = ctl(S, level, 2 + 2 * g);
+        sa.shadow.seg_capacity = bd.in.seg_capacity * kLightGroup;
         sa.shadow.overflow = overflow_flag(S);
         HIP_TRY(rt::launch_shade(sd, sa, kBounceBlocks, st));
         if (S->l_size > 0) {
           rt::WalkArgs ws;
           memset(&ws, 0, sizeof ws);
           ws.in = sa.shadow;
-          ws.cursor = ctl(S, level, 4 + 2 * l);
+          ws.cursor = ctl(S, level, 3 + 2 * g);
           ws.extra = S->extra.p;
           ws.ray_count = dev_ray_count;
           HIP_TRY(rt::launch_walk(sd, ws, true, kBounceBlocks, st));

@@ -23,7 +23,7 @@ struct BvhNode {
                       // closer to the world origin than this
 };
 constexpr int32_t BVH_EMPTY = 0x7fffffff;
-constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_LEAF_MAX = 1;
 constexpr int BVH_STACK = 40;
 
 struct BvhHost {

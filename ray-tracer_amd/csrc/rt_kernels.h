@@ -55,12 +55,10 @@ struct RayQueue {
   uint32_t *overflow; // set to 1 when a ray had to be dropped
 };
 
-// Compact list of nearest hits, segmented like the queue the rays came from.
+// Nearest sphere hit of every ray of a level, at the ray's own queue slot.
 struct HitList {
-  float4 *rec;        // P.xyz, bits of (kind << 28 | index)
-  uint32_t *ray;      // global queue slot of the ray that hit
-  uint32_t *count;    // count[s * CTL_WORDS]
-  uint32_t seg_capacity;
+  float4 *rec;  // P.xyz, |P|
+  int32_t *idx; // sphere index, -1 = no sphere hit
 };
 
 struct BounceDev {
@@ -81,13 +79,14 @@ struct WalkArgs {
 };
 
 struct ShadeArgs {
-  RayQueue rays;     // the level's rays (read through HitList::ray)
-  HitList hits;
-  int light;         // light to evaluate in this launch, or -1
+  RayQueue rays;     // the level's rays
+  HitList hits;      // their nearest sphere hits (k_walk)
+  int light_begin, light_end; // lights evaluated in this launch
   int spawn;         // also queue the next level's rays
   int max_depth;
-  RayQueue shadow;   // shadow-ray items for `light`
+  RayQueue shadow;   // shadow-ray items that no triangle blocks
   RayQueue next;     // next level's rays
+  uint64_t *ray_count;
 };
 
 struct CheckArgs {

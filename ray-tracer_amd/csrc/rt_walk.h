@@ -59,6 +59,40 @@ __device__ __forceinline__ void add_light(uint32_t *extra, uint32_t pixel, uint3
     atomicAdd(extra + 3 * (size_t)pixel + 2, c2);
 }
 
+// One exact sphere test for a lane's ray against leaf slot `slot`, folded into
+// the lane's running nearest sphere hit (smallest |P|, lowest index on ties:
+// the order-free form of renderer.cpp:168-177).  Returns true on an accepted hit.
+__device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a, float a4,
+                                          float ox, float oy, float oz, float dx, float dy,
+                                          float dz, float &len_s, int &idx_s, float &sPx,
+                                          float &sPy, float &sPz) {
+  const float4 g = sc.leaf_geo[slot];
+  float Px, Py, Pz;
+  if (!sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py, Pz))
+    return false;
+  const float len = length3(Px, Py, Pz);
+  const int idx = sc.leaf_idx[slot];
+  if (len < RT_INF && (len < len_s || (len == len_s && idx < idx_s))) {
+    len_s = len;
+    idx_s = idx;
+    sPx = Px;
+    sPy = Py;
+    sPz = Pz;
+    return true;
+  }
+  return false;
+}
+
+// k_walk — spheres only.  Each lane walks the hierarchy for one queue item at a
+// time and fetches the next item when it is done.
+//   ANY_HIT = false: item = bounce ray; result (P, |P|, sphere index or -1) is
+//                    written to hits[slot of the ray]
+//   ANY_HIT = true : item = shadow ray (tagA = pixel, tagB = packed light);
+//                    the light is added to the pixel if no sphere is hit
+// Leaves are single spheres.  Running the exact test the moment a leaf is touched
+// would make every iteration of the wave pay for it with one or two lanes
+// active, so a lane parks up to four touched leaves and the whole wave works
+// them off together whenever it stops to refill.
 template <bool ANY_HIT>
 __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   const int lane = threadIdx.x & 63;
@@ -70,135 +104,111 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
     n_in = w.in.seg_capacity;
   const size_t seg_base = (size_t)seg * w.in.seg_capacity;
   uint32_t *const cursor = w.cursor + seg * CTL_WORDS;
-  uint32_t *const n_hits = ANY_HIT ? nullptr : w.hits.count + seg * CTL_WORDS;
-  const size_t hit_base = ANY_HIT ? 0 : (size_t)seg * w.hits.seg_capacity;
 
-  // lane state
-  enum { EMPTY = 0, BUSY = 1, FINISHED = 2 };
+  enum { EMPTY = 0, BUSY = 1, DRAIN = 2 }; // DRAIN: walk over, parked leaves left
   int state = EMPTY;
   uint32_t ray = 0, tagA = 0, tagB = 0;
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, a = 0, a4 = 0, da = 0;
-  float len_t = RT_INF, len_s = RT_INF, bound = RT_INF;
-  int idx_t = -1, idx_s = -1;
-  float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
+  float len_s = RT_INF, bound = RT_INF;
+  int idx_s = -1;
+  float sPx = 0, sPy = 0, sPz = 0;
   int stack[BVH_STACK];
   int sp = 0, node = 0;
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0, n_park = 0;
   uint32_t n_rays = 0;
   bool drained = false;
 
   while (true) {
-    const unsigned long long not_busy = __ballot(state != BUSY);
-    const int n_free = __builtin_popcountll(not_busy);
+    const int n_free = __builtin_popcountll(__ballot(state != BUSY));
     if (n_free == 64 || (!drained && n_free >= WALK_FETCH_AT)) {
-      // ---- hand in finished rays ----
-      if (!ANY_HIT) {
-        // renderer.cpp:179-192: nothing / triangle (wins ties) / sphere
-        int kind = 0, index = -1;
-        float Px = 0, Py = 0, Pz = 0;
-        if (state == FINISHED && (idx_t >= 0 || idx_s >= 0)) {
-          if (len_t <= len_s) {
-            kind = 1;
-            index = idx_t;
-            Px = tPx;
-            Py = tPy;
-            Pz = tPz;
-          } else if (len_t > len_s) {
-            kind = 2;
-            index = idx_s;
-            Px = sPx;
-            Py = sPy;
-            Pz = sPz;
-          }
-        }
-        const bool push = kind != 0;
-        const unsigned long long m = __ballot(push);
-        if (m) {
-          const int leader = __builtin_ctzll(m);
-          uint32_t base = 0;
-          if (lane == leader)
-            base = atomicAdd(n_hits, (uint32_t)__builtin_popcountll(m));
-          base = __builtin_amdgcn_readlane(base, leader);
-          if (push) {
-            const uint32_t slot =
-                base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            // a segment of hits is as long as its segment of rays: it cannot overflow
-            w.hits.rec[hit_base + slot] =
-                make_float4(Px, Py, Pz, __uint_as_float(((uint32_t)kind << 28) | (uint32_t)index));
-            w.hits.ray[hit_base + slot] = (uint32_t)(seg_base + ray);
+      // ---- work off parked leaves, all lanes together ----
+      while (__any(n_park > 0)) {
+        if (n_park > 0) {
+          const int slot = n_park == 1 ? p0 : n_park == 2 ? p1 : n_park == 3 ? p2 : p3;
+          n_park--;
+          if (!(ANY_HIT && idx_s >= 0) &&
+              leaf_test(sc, slot, a, a4, ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy, sPz)) {
+            if (ANY_HIT)
+              state = DRAIN; // occluded: nothing more to find
+            else
+              bound = fminf(bound, len_s);
           }
         }
       }
-      if (state == FINISHED)
+      // ---- hand in finished items ----
+      if (state == DRAIN) {
+        if (ANY_HIT) {
+          if (idx_s < 0) // unoccluded: renderer.cpp:119-127, as an integer sum
+            add_light(w.extra, tagA, tagB);
+        } else {
+          w.hits.rec[seg_base + ray] = make_float4(sPx, sPy, sPz, len_s);
+          w.hits.idx[seg_base + ray] = idx_s;
+        }
         state = EMPTY;
-      // ---- fetch new rays ----
+      }
+      // ---- fetch ----
       if (!drained) {
         const unsigned long long e = __ballot(state == EMPTY);
         const int n_e = __builtin_popcountll(e);
-        const int leader = __builtin_ctzll(e);
-        uint32_t base = 0;
-        if (lane == leader)
-          base = atomicAdd(cursor, (uint32_t)n_e);
-        base = __builtin_amdgcn_readlane(base, leader);
-        if (base + (uint32_t)n_e >= n_in)
-          drained = true;
-        if (state == EMPTY) {
-          const uint32_t r = base + (uint32_t)__builtin_popcountll(e & ((1ull << lane) - 1ull));
-          if (r < n_in) {
-            const float4 qa = w.in.items[2 * (seg_base + r)],
-                         qb = w.in.items[2 * (seg_base + r) + 1];
-            ray = r;
-            ox = qa.x;
-            oy = qa.y;
-            oz = qa.z;
-            tagA = __float_as_uint(qa.w);
-            dx = qb.x;
-            dy = qb.y;
-            dz = qb.z;
-            tagB = __float_as_uint(qb.w);
-            n_rays++;
-            len_t = len_s = RT_INF;
-            idx_t = idx_s = -1;
-            lane_triangles(sc, ANY_HIT, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
-            a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
-            a4 = 4.0f * a;
-            da = sqrtf(a) * 1.000244140625f;
-            bound = ANY_HIT ? RT_INF : len_t;
-            sp = 0;
-            node = 0;
-            state = BUSY;
-            const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
-            if ((ANY_HIT && idx_t >= 0) || !(a > 0.f) || sc.s_size == 0) {
-              state = FINISHED; // occluded by a triangle / no sphere can be hit
-            } else if (!sane || sc.bvh == nullptr) {
-              // out-of-range direction length: this lane tests every sphere
-              for (int i = 0; i < sc.s_size && state == BUSY; i++) {
-                const float4 g = sc.sph_geo[i];
-                float Px, Py, Pz;
-                if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
-                  const float len = length3(Px, Py, Pz);
-                  if (len_s > len) {
-                    len_s = len;
-                    idx_s = i;
-                    sPx = Px;
-                    sPy = Py;
-                    sPz = Pz;
-                    if (ANY_HIT)
-                      state = FINISHED;
+        if (n_e) {
+          const int leader = __builtin_ctzll(e);
+          uint32_t base = 0;
+          if (lane == leader)
+            base = atomicAdd(cursor, (uint32_t)n_e);
+          base = __builtin_amdgcn_readlane(base, leader);
+          if (base + (uint32_t)n_e >= n_in)
+            drained = true;
+          if (state == EMPTY) {
+            const uint32_t r = base + (uint32_t)__builtin_popcountll(e & ((1ull << lane) - 1ull));
+            if (r < n_in) {
+              const float4 qa = w.in.items[2 * (seg_base + r)],
+                           qb = w.in.items[2 * (seg_base + r) + 1];
+              ray = r;
+              ox = qa.x;
+              oy = qa.y;
+              oz = qa.z;
+              tagA = __float_as_uint(qa.w);
+              dx = qb.x;
+              dy = qb.y;
+              dz = qb.z;
+              tagB = __float_as_uint(qb.w);
+              n_rays++;
+              len_s = RT_INF;
+              idx_s = -1;
+              a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
+              a4 = 4.0f * a;
+              da = __builtin_amdgcn_sqrtf(a) * 1.001f; // >= |d|
+              bound = RT_INF;
+              sp = 0;
+              node = 0;
+              n_park = 0;
+              state = BUSY;
+              const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
+              if (!(a > 0.f) || sc.s_size == 0) {
+                state = DRAIN; // no sphere can be hit (rt_device.h, beam screen notes)
+              } else if (!sane || sc.bvh == nullptr) {
+                // out-of-range direction length: this lane tests every sphere
+                for (int i = 0; i < sc.s_size; i++) {
+                  const float4 g = sc.sph_geo[i];
+                  float Px, Py, Pz;
+                  if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
+                    const float len = length3(Px, Py, Pz);
+                    if (len_s > len) {
+                      len_s = len;
+                      idx_s = i;
+                      sPx = Px;
+                      sPy = Py;
+                      sPz = Pz;
+                      if (ANY_HIT)
+                        break;
+                    }
                   }
                 }
+                state = DRAIN;
               }
-              state = FINISHED;
             }
           }
         }
-      }
-      if (ANY_HIT && state == FINISHED) {
-        // shadow ray done before walking: occluded by a triangle, or unoccluded
-        // with no sphere able to block it
-        if (idx_t < 0 && idx_s < 0) {
-          add_light(w.extra, tagA, tagB);
-        }
-        state = EMPTY;
       }
       if (!__any(state != EMPTY))
         break;
@@ -206,79 +216,69 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
     }
 
     if (state == BUSY) {
-      // ---- one node visit (see trace<..., RT_ACCEL_BVH> in rt_device.h) ----
+      // ---- one node visit: both children's bounds (see bvh_touches) ----
       const BvhNode N = sc.bvh[node];
-      int next = -1;
-      bool done = false;
-      const bool swap = N.near1 < N.near0;
+      const bool t0 = N.link0 != BVH_EMPTY &&
+                      bvh_touches(N.s0, N.near0, ox, oy, oz, dx, dy, dz, a, da, bound);
+      const bool t1 = N.link1 != BVH_EMPTY &&
+                      bvh_touches(N.s1, N.near1, ox, oy, oz, dx, dy, dz, a, da, bound);
+      // touched leaves are parked (or, with four already parked, tested now)
 #pragma unroll
-      for (int cc = 0; cc < 2; cc++) {
-        const bool c = (cc != 0) != swap;
-        const float4 s = c ? N.s1 : N.s0;
-        const float near = c ? N.near1 : N.near0;
+      for (int c = 0; c < 2; c++) {
+        const bool t = c ? t1 : t0;
         const int32_t link = c ? N.link1 : N.link0;
-        if (link == BVH_EMPTY || !bvh_touches(s, near, ox, oy, oz, dx, dy, dz, a, da, bound))
-          continue;
-        if (link >= 0) {
-          if (next < 0)
-            next = link;
-          else if (sp < BVH_STACK)
-            stack[sp++] = link;
-        } else {
-          const int v = ~link, first = v >> 3, count = (v & 7) + 1;
-          for (int k = 0; k < count; k++) {
-            const float4 g = sc.leaf_geo[first + k];
-            float Px, Py, Pz;
-            if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
-              const float len = length3(Px, Py, Pz);
-              const int idx = sc.leaf_idx[first + k];
-              if (len < RT_INF && (len < len_s || (len == len_s && idx < idx_s))) {
-                len_s = len;
-                idx_s = idx;
-                sPx = Px;
-                sPy = Py;
-                sPz = Pz;
-                if (ANY_HIT)
-                  done = true;
-                else
-                  bound = fminf(bound, len);
-              }
-            }
+        if (t && link < 0) {
+          const int slot = (~link) >> 3;
+          if (n_park < 4) {
+            if (n_park == 0)
+              p0 = slot;
+            else if (n_park == 1)
+              p1 = slot;
+            else if (n_park == 2)
+              p2 = slot;
+            else
+              p3 = slot;
+            n_park++;
+          } else if (leaf_test(sc, slot, a, a4, ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy,
+                               sPz)) {
+            if (!ANY_HIT)
+              bound = fminf(bound, len_s);
           }
         }
       }
-      if (!done) {
-        if (next >= 0)
-          node = next;
-        else if (sp > 0)
-          node = stack[--sp];
-        else
-          done = true;
+      const bool in0 = t0 && N.link0 >= 0, in1 = t1 && N.link1 >= 0;
+      // descend into the child nearer to the world origin first: it tightens bound
+      const bool first1 = in1 && (!in0 || N.near1 < N.near0);
+      int next = -1;
+      if (in0 || in1) {
+        next = first1 ? N.link1 : N.link0;
+        if (in0 && in1 && sp < BVH_STACK)
+          stack[sp++] = first1 ? N.link0 : N.link1;
+      } else if (sp > 0) {
+        next = stack[--sp];
       }
-      if (done) {
-        if (ANY_HIT) {
-          if (idx_s < 0) { // unoccluded: renderer.cpp:119-127, as an integer sum
-            add_light(w.extra, tagA, tagB);
-          }
-          state = EMPTY;
-        } else {
-          state = FINISHED;
-        }
-      }
+      if (next >= 0 && !(ANY_HIT && idx_s >= 0))
+        node = next;
+      else
+        state = DRAIN;
     }
   }
   add_ray_count(w.ray_count, n_rays);
 }
 
-// One hit of a bounce ray per lane: surface, material, then for light `light`
-// the Phong term as a shadow-ray item; with spawn set, the next level's rays.
+// k_shade — one ray of the level per lane: the triangles (renderer.cpp:156-166),
+// the choice between nearest triangle and nearest sphere (renderer.cpp:179-192),
+// then shading: per light the Phong term and the shadow ray, whose triangle test
+// also runs here so that only rays a triangle does not already block go on to
+// the sphere walk; finally the next level's rays.
 __global__ __launch_bounds__(256) void k_shade(SceneDev sc, ShadeArgs s) {
   const uint32_t seg = my_segment();
-  uint32_t n = s.hits.count[seg * CTL_WORDS];
-  if (n > s.hits.seg_capacity)
-    n = s.hits.seg_capacity;
-  const size_t hit_base = (size_t)seg * s.hits.seg_capacity;
+  uint32_t n = s.rays.count[seg * CTL_WORDS];
+  if (n > s.rays.seg_capacity)
+    n = s.rays.seg_capacity;
+  const size_t seg_base = (size_t)seg * s.rays.seg_capacity;
   const uint32_t stride = (gridDim.x / QUEUE_SEGMENTS) * blockDim.x;
+  uint32_t n_rays = 0;
   for (uint32_t base = (blockIdx.x / QUEUE_SEGMENTS) * blockDim.x + (threadIdx.x & ~63u); base < n;
        base += stride) {
     const uint32_t i = base + (threadIdx.x & 63);
@@ -287,29 +287,48 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, ShadeArgs s) {
     h.kind = 0;
     h.index = -1;
     h.Px = h.Py = h.Pz = 0;
-    float dx = 0, dy = 0, dz = 0, wgt = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, wgt = 0;
     uint32_t pixel = 0, depth = 0;
     if (live) {
-      const float4 hr = s.hits.rec[hit_base + i];
-      const uint32_t r = s.hits.ray[hit_base + i];
-      const float4 qa = s.rays.items[2 * (size_t)r], qb = s.rays.items[2 * (size_t)r + 1];
-      const uint32_t ki = __float_as_uint(hr.w);
-      h.kind = (int)(ki >> 28);
-      h.index = (int)(ki & 0x0fffffffu);
-      h.Px = hr.x;
-      h.Py = hr.y;
-      h.Pz = hr.z;
+      const float4 qa = s.rays.items[2 * (seg_base + i)], qb = s.rays.items[2 * (seg_base + i) + 1];
+      ox = qa.x;
+      oy = qa.y;
+      oz = qa.z;
+      wgt = qa.w;
       dx = qb.x;
       dy = qb.y;
       dz = qb.z;
-      wgt = qa.w;
       const uint32_t tag = __float_as_uint(qb.w);
       pixel = tag >> 6;
       depth = tag & 63u;
+      const float4 sh = s.hits.rec[seg_base + i];
+      const int idx_s = s.hits.idx[seg_base + i];
+      const float len_s = idx_s >= 0 ? sh.w : RT_INF;
+      float len_t = RT_INF, tPx = 0, tPy = 0, tPz = 0;
+      int idx_t = -1;
+      lane_triangles(sc, false, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
+      if (idx_t >= 0 || idx_s >= 0) { // renderer.cpp:179-192
+        if (len_t <= len_s) {
+          h.kind = 1;
+          h.index = idx_t;
+          h.Px = tPx;
+          h.Py = tPy;
+          h.Pz = tPz;
+        } else if (len_t > len_s) {
+          h.kind = 2;
+          h.index = idx_s;
+          h.Px = sh.x;
+          h.Py = sh.y;
+          h.Pz = sh.z;
+        }
+      }
     }
+    const bool hit = live && h.kind != 0;
+    if (!__any(hit))
+      continue;
     Surface sf;
     float kr = 0.f, kt = 0.f, ior = 1.f, wl = 0.f;
-    if (live) {
+    if (hit) {
       sf = surface_at(sc, h);
       const float4 m = material_at(sc, h);
       kr = m.x;
@@ -317,22 +336,35 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, ShadeArgs s) {
       ior = m.z > 0.f ? m.z : 1.0f;
       wl = wgt * ((1.0f - kr) - kt);
     }
-    const bool lit = live && wl >= RT_MIN_WEIGHT;
-    if (s.light >= 0 && __any(lit)) {
-      float fColor[3] = {0, 0, 0};
-      float lx = 0, ly = 0, lz = 0, angle = 0;
-      if (lit)
-        angle = phong_light(sf, h, dx, dy, dz, sc.lights[s.light], fColor, lx, ly, lz);
-      const uint32_t c0 = (uint32_t)((fColor[0] * angle) * wl), c1 = (uint32_t)((fColor[1] * angle) * wl),
-                     c2 = (uint32_t)((fColor[2] * angle) * wl);
-      // the shadow item: origin exactly P (renderer.cpp:119), tagA = pixel,
-      // tagB = the three integer contributions (each <= 255), 10 bits apiece
-      const uint32_t packed = (c0 & 0x3ffu) | ((c1 & 0x3ffu) << 10) | ((c2 & 0x3ffu) << 20);
-      queue_push_raw(s.shadow, lit, make_float4(h.Px, h.Py, h.Pz, __uint_as_float(pixel)),
-                     make_float4(lx, ly, lz, __uint_as_float(packed)));
+    const bool lit = hit && wl >= RT_MIN_WEIGHT;
+    if (__any(lit)) {
+      for (int l = s.light_begin; l < s.light_end; l++) {
+        float fColor[3] = {0, 0, 0};
+        float lx = 0, ly = 0, lz = 0, angle = 0;
+        bool blocked = false;
+        if (lit) {
+          angle = phong_light(sf, h, dx, dy, dz, sc.lights[l], fColor, lx, ly, lz);
+          // renderer.cpp:119: the shadow ray starts exactly at P; its triangles here
+          float len_t = RT_INF, tx, ty, tz;
+          int idx_t = -1;
+          lane_triangles(sc, true, h.Px, h.Py, h.Pz, lx, ly, lz, len_t, idx_t, tx, ty, tz);
+          blocked = idx_t >= 0;
+          if (blocked)
+            n_rays++; // traced to the end here; the others are counted by the walk
+        }
+        const uint32_t c0 = (uint32_t)((fColor[0] * angle) * wl),
+                       c1 = (uint32_t)((fColor[1] * angle) * wl),
+                       c2 = (uint32_t)((fColor[2] * angle) * wl);
+        // the shadow item: tagA = pixel, tagB = the three integer contributions
+        // (each <= 255), 10 bits apiece
+        const uint32_t packed = (c0 & 0x3ffu) | ((c1 & 0x3ffu) << 10) | ((c2 & 0x3ffu) << 20);
+        queue_push_raw(s.shadow, lit && !blocked,
+                       make_float4(h.Px, h.Py, h.Pz, __uint_as_float(pixel)),
+                       make_float4(lx, ly, lz, __uint_as_float(packed)));
+      }
     }
     if (s.spawn) {
-      const bool deeper = live && (int)depth < s.max_depth;
+      const bool deeper = hit && (int)depth < s.max_depth;
       const bool want_t = deeper && kt > 0.f && (wgt * kt >= RT_MIN_WEIGHT);
       const bool want_r = deeper && kr > 0.f && (wgt * kr >= RT_MIN_WEIGHT);
       if (__any(want_t)) {
@@ -351,6 +383,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, ShadeArgs s) {
       }
     }
   }
+  add_ray_count(s.ray_count, n_rays);
 }
 
 } // namespace rt

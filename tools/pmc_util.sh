@@ -6,11 +6,11 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIV
 python3 - $OUT <<'PY'
 import sqlite3, glob, sys
 con=sqlite3.connect(glob.glob(sys.argv[1]+"/*.db")[0])
-q="select kernel_name, dispatch_id, counter_name, value from counters_collection where kernel_name like '%k_bounce<true%' or kernel_name like '%k_render<3%' order by dispatch_id"
+q="select kernel_name, dispatch_id, counter_name, value from counters_collection where kernel_name like '%rt::k_%' order by dispatch_id"
 d={}
 for k,i,c,v in con.execute(q):
     d.setdefault((i,k[:30]),{})[c]=v
-for (i,k),c in list(d.items())[:10]:
+for (i,k),c in list(d.items())[3:16]:
     lanes = c['SQ_THREAD_CYCLES_VALU']/max(1,c['SQ_ACTIVE_INST_VALU'])/4 if 'SQ_THREAD_CYCLES_VALU' in c else -1
     print(i,k, "VALU insts %.3g thread_cycles %.3g active %.3g -> lanes/instr %.1f ; wave_cycles %.3g wait_any %.0f%% vmem_rd %.3g vmem_wr %.3g"%(c['SQ_INSTS_VALU'],c['SQ_THREAD_CYCLES_VALU'],c['SQ_ACTIVE_INST_VALU'],lanes,c['SQ_WAVE_CYCLES'],100*c['SQ_WAIT_ANY']/c['SQ_WAVE_CYCLES'],c['SQ_INSTS_VMEM_RD'],c['SQ_INSTS_VMEM_WR']))
 PY
