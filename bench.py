@@ -110,38 +110,59 @@ def main():
     ds = rtamd.DeviceScene(sc)
     rtamd.set_screen(args.screen)
     send, recv = plan.alloc_gather(dev)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    kernel_ms = []
+    # A second frame buffer lets the gather of frame k overlap the render of
+    # frame k+1 (the gather runs on the communicator's own stream).
+    n_buf = 2 if world > 1 else 1
+    fbs = [fb] + [plan.alloc_frame(dev) for _ in range(n_buf - 1)]
+    gath = [(send, recv)] + [plan.alloc_gather(dev) for _ in range(n_buf - 1)]
+    events = []     # (start, end) pairs around the device work of each timed frame
+    pending = [None] * n_buf
 
-    def step(timed):
+    def finish(b):
+        """Frame in buffer b: wait for its gather and, on rank 0, put the other
+        ranks' bands in place.  The frame is then complete on GPU 0."""
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+            plan.scatter_received(fbs[b], gath[b][1])
+
+    def step(timed, k=0):
+        b = k % n_buf
+        finish(b)
         if timed:
-            ev0.record()
-        ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth, band_rows=band_rows,
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ds.render_device(fbs[b].data_ptr(), None, w, h, max_depth=depth, band_rows=band_rows,
                          band_index=rank, band_count=world, stream=stream,
                          dev_ray_count=cnt.data_ptr())
         if timed:
-            ev1.record()
-        plan.gather_to_rank0(fb, send, recv)
-        if timed:
-            ev1.synchronize()
-            kernel_ms.append(ev0.elapsed_time(ev1))
+            e1.record()
+            events.append((e0, e1))
+        pending[b] = plan.gather_to_rank0(fbs[b], gath[b][0], gath[b][1], async_op=True)
 
-    for _ in range(args.warmup):
-        step(False)
+    def drain():
+        for b in range(n_buf):
+            finish(b)
+
+    for k in range(args.warmup):
+        step(False, k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     cnt.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        step(True, k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in events]
 
     rays = cnt.clone()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -171,8 +192,11 @@ def main():
                        "sharding": f"row bands of {band_rows}, round-robin over {world} GPU(s)"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved,
                          "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                         "kernel": "k_render", "kernel_ms": k_ms,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": measured_traffic(name),
+                         "kernel": "device work of one rt_render_device call: k_render, then per "
+                                   "bounce level k_walk / k_shade / k_walk, k_compose",
+                         "kernel_ms": k_ms,
                          "flop_per_ray": n_tests_per_ray,
                          "note": "algorithmic FLOP = rays x (25 x spheres + 107 x triangles); "
                                  "parity forbids FMA, so 1 flop/lane/instr caps executed "
@@ -187,11 +211,12 @@ def main():
             rtamd.set_screen(False)
             step(False)
             torch.cuda.synchronize()
-            kernel_ms.clear()
+            events.clear()
             for _ in range(2):
                 step(True)
+            torch.cuda.synchronize()
             rtamd.set_screen(args.screen)
-            bf_ms = float(np.mean(kernel_ms))
+            bf_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
             bf = my_rays_per_launch * n_tests_per_ray / (bf_ms * 1e-3) / 1e12
             out["roofline"]["plain_loop"] = {
                 "kernel_ms": bf_ms, "achieved": bf, "frac": bf / PEAK_FP32_VALU_TFLOPS,
@@ -202,6 +227,17 @@ def main():
     ds.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(workload):
+    """HBM bytes per frame from rocprofv3 counters (FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE), collected by tools/profile.sh in a run of its own and kept in
+    profiles/traffic.json; None when that workload has not been profiled."""
+    try:
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_frame")
+    except (OSError, ValueError):
+        return None
 
 
 def default_workload():

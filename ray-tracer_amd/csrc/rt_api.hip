@@ -80,7 +80,7 @@ struct rt_scene {
   // per light {shadow items, shadow cursor}; the very last word is the overflow flag
   DevBuf<uint32_t> counts;
   int ctl_rows = 0; // rows per level
-  DevBuf<uint32_t> extra;  // 3 per pixel
+  DevBuf<unsigned long long> extra; // per pixel, 3 x 21 bits
   DevBuf<float4> hit_rec, shadow_items;
   DevBuf<int32_t> hit_idx;
   size_t queue_capacity = 0, extra_pixels = 0;
@@ -275,8 +275,8 @@ int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels)
     HIP_TRY(S->counts.alloc((size_t)kLevels * S->ctl_rows * kRowWords + 1));
   }
   if (S->extra_pixels < frame_pixels) {
-    HIP_TRY(S->extra.alloc(3 * frame_pixels));
-    HIP_TRY(hipMemset(S->extra.p, 0, 3 * frame_pixels * sizeof(uint32_t)));
+    HIP_TRY(S->extra.alloc(frame_pixels));
+    HIP_TRY(hipMemset(S->extra.p, 0, frame_pixels * sizeof(unsigned long long)));
     S->extra_pixels = frame_pixels;
   }
   return RT_OK;
@@ -375,6 +375,8 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
                 band_count);
   if (fr->max_depth > kMaxDepth)
     return fail(RT_ERR_BAD_ARG, "max_depth %d > %d", fr->max_depth, kMaxDepth);
+  if (fr->max_depth > 1 && S->l_size > 8000)
+    return fail(RT_ERR_UNSUPPORTED, "bounces with more than 8000 lights (21-bit light sums)");
   hipStream_t st = (hipStream_t)fr->stream;
   HIP_TRY(hipSetDevice(S->device));
   int rc = scene_set_eye(S, cam, st);

@@ -64,7 +64,7 @@ struct HitList {
 struct BounceDev {
   RayQueue in;     // rays to trace at this level (unused by k_render)
   RayQueue out;    // rays spawned for the next level
-  uint32_t *extra; // 3 x uint32 per pixel: integer light of bounce hits
+  unsigned long long *extra; // per pixel: integer light of bounce hits, 3 x 21 bits
   int max_depth;   // 1 = no bounces (all other fields may be null)
 };
 
@@ -73,8 +73,8 @@ struct WalkArgs {
   RayQueue in;        // items to walk: (origin, tagA bits), (direction, tagB bits)
   uint32_t *cursor;   // cursor[s * CTL_WORDS]: next item of segment s to hand out
   HitList hits;       // nearest-hit walks: where hits go
-  uint32_t *extra;    // shadow walks: tagA = pixel, tagB = packed integer light,
-                      // added to the pixel if unoccluded
+  unsigned long long *extra; // shadow walks: tagA = pixel, tagB = packed integer
+                             // light, added to the pixel if unoccluded
   uint64_t *ray_count;
 };
 
@@ -117,7 +117,7 @@ hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
 hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, int blocks,
                        hipStream_t st);
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st);
-hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
+hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st);
 hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
                                 float4 *leaf_geo, int n, hipStream_t st);

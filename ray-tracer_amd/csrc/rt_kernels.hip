@@ -303,13 +303,10 @@ shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
             fb1 = accumulate_u8(fb1, a1);
             fb2 = accumulate_u8(fb2, a2);
           } else {
-            uint32_t c0 = (uint32_t)a0, c1 = (uint32_t)a1, c2 = (uint32_t)a2;
-            if (c0)
-              atomicAdd(bd.extra + 3 * (size_t)pixel + 0, c0);
-            if (c1)
-              atomicAdd(bd.extra + 3 * (size_t)pixel + 1, c1);
-            if (c2)
-              atomicAdd(bd.extra + 3 * (size_t)pixel + 2, c2);
+            const unsigned long long c0 = (uint32_t)a0, c1 = (uint32_t)a1, c2 = (uint32_t)a2;
+            const unsigned long long v = c0 | (c1 << 21) | (c2 << 42);
+            if (v)
+              atomicAdd(bd.extra + pixel, v);
           }
         }
       }
@@ -452,22 +449,22 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
 
 // Pixel = saturating sum of the primary hit's light (already in fb) and the
 // integer side sums of all bounce hits; the side sums are cleared for reuse.
-__global__ void k_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels) {
+__global__ void k_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels) {
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pixels)
     return;
-  uint32_t e0 = extra[3 * p], e1 = extra[3 * p + 1], e2 = extra[3 * p + 2];
-  if ((e0 | e1 | e2) == 0)
+  const unsigned long long e = extra[p];
+  if (e == 0)
     return;
+  const uint32_t e0 = (uint32_t)(e & 0x1fffffu), e1 = (uint32_t)((e >> 21) & 0x1fffffu),
+                 e2 = (uint32_t)((e >> 42) & 0x1fffffu);
   uchar4 c = reinterpret_cast<uchar4 *>(fb)[p];
   uint32_t v0 = c.x + e0, v1 = c.y + e1, v2 = c.z + e2;
   c.x = (unsigned char)(v0 > 255u ? 255u : v0);
   c.y = (unsigned char)(v1 > 255u ? 255u : v1);
   c.z = (unsigned char)(v2 > 255u ? 255u : v2);
   reinterpret_cast<uchar4 *>(fb)[p] = c;
-  extra[3 * p] = 0;
-  extra[3 * p + 1] = 0;
-  extra[3 * p + 2] = 0;
+  extra[p] = 0;
 }
 
 } // namespace rt
@@ -586,7 +583,7 @@ hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipS
   return hipGetLastError();
 }
 
-hipError_t launch_compose(uint8_t *fb, uint32_t *extra, size_t n_pixels,
+hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st) {
   hipLaunchKernelGGL(k_compose, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0,
                      st, fb, extra, n_pixels);

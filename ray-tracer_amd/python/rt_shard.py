@@ -44,15 +44,26 @@ class BandPlan:
             recv = [torch.empty_like(send) for _ in range(self.world)]
         return send, recv
 
-    def gather_to_rank0(self, fb: torch.Tensor, send: torch.Tensor, recv) -> None:
-        """Moves every rank's bands into rank 0's `fb`.  No-op for world == 1."""
+    def gather_to_rank0(self, fb: torch.Tensor, send: torch.Tensor, recv, async_op: bool = False):
+        """Moves every rank's bands into rank 0's `fb`.  No-op for world == 1.
+        With async_op the collective's work handle is returned and rank 0 must
+        call scatter_received() after waiting on it."""
         if self.world == 1:
-            return
+            return None
         bands = fb.view(self.n_bands, self.band_bytes)
         mine = bands[self.rank::self.world]
         send[:mine.shape[0]].copy_(mine)
-        dist.gather(send, recv, dst=0)
-        if self.rank == 0:
-            for r in range(1, self.world):
-                k = len(self.owned(r))
-                bands[r::self.world].copy_(recv[r][:k])
+        work = dist.gather(send, recv, dst=0, async_op=async_op)
+        if async_op:
+            return work
+        self.scatter_received(fb, recv)
+        return None
+
+    def scatter_received(self, fb: torch.Tensor, recv) -> None:
+        """Rank 0: places the gathered bands of the other ranks into `fb`."""
+        if self.world == 1 or self.rank != 0:
+            return
+        bands = fb.view(self.n_bands, self.band_bytes)
+        for r in range(1, self.world):
+            k = len(self.owned(r))
+            bands[r::self.world].copy_(recv[r][:k])

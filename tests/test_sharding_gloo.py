@@ -41,7 +41,12 @@ def _worker(rank, world, port, w, h, band_rows, out_path):
         part, _, _ = o.render(sc, w, h, rows=(r0, r1, 1), want_ids=False)
         fb[r0:r1] = torch.from_numpy(part[r0:r1])
     send, recv = plan.alloc_gather("cpu")
-    plan.gather_to_rank0(fb, send, recv)
+    if band_rows == 8:
+        plan.gather_to_rank0(fb, send, recv)
+    else:  # the overlapped form bench.py uses
+        work = plan.gather_to_rank0(fb, send, recv, async_op=True)
+        work.wait()
+        plan.scatter_received(fb, recv)
     if rank == 0:
         np.save(out_path, fb[:h].numpy())
     dist.barrier()

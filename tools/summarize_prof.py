@@ -22,7 +22,8 @@ for db in dbs:
         print(f"== kernel time (rocprofv3 --kernel-trace --stats): {rel}")
         print(f"   {'kernel':72s} {'calls':>6s} {'total_ms':>11s} {'avg_ms':>10s} {'%':>6s}")
         for name, calls, total, avg, pct in rows:
-            print(f"   {name[:72]:72s} {calls:6d} {total/1e6:11.3f} {avg/1e6:10.4f} {pct:6.2f}")
+            # the top_kernels view reports microseconds
+            print(f"   {name[:72]:72s} {calls:6d} {total/1e3:11.3f} {avg/1e3:10.4f} {pct:6.2f}")
     if n_pmc:
         print(f"== counters (rocprofv3 --pmc), mean per dispatch: {rel}")
         q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
