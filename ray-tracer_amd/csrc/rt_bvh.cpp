@@ -1,5 +1,6 @@
 // rt_bvh.cpp — host-side construction of the bounding-sphere hierarchy
-// (median split on the longest axis of the centres' bounding box).
+// (two rounds of median splits on the longest axis of the centres' bounding
+// box per node: up to four children; one sphere per leaf).
 #include "rt_bvh.h"
 
 #include <algorithm>
@@ -58,35 +59,67 @@ struct Builder {
     return f;
   }
 
-  // Returns the link for order[b, e) and its bounding sphere.
-  int32_t build(int b, int e, float4 &sphere) {
+  void split(int b, int e, int &m) {
     int axis;
-    sphere = bound(b, e, axis);
-    const int n = e - b;
-    if (n <= BVH_LEAF_MAX) {
-      const int first = (int)out->leaf_idx.size();
-      for (int k = b; k < e; k++)
-        out->leaf_idx.push_back(order[k]);
-      return ~((first << 3) | (n - 1));
-    }
-    const int m = b + n / 2;
+    (void)bound(b, e, axis);
+    m = b + (e - b) / 2;
     std::nth_element(order.begin() + b, order.begin() + m, order.begin() + e,
                      [&](int32_t x, int32_t y) {
                        float vx = c[3 * x + axis], vy = c[3 * y + axis];
                        return vx < vy || (vx == vy && x < y);
                      });
+  }
+
+  // Returns the link for order[b, e) and its bounding sphere.
+  int32_t build(int b, int e, float4 &sphere) {
+    int axis;
+    sphere = bound(b, e, axis);
+    const int n = e - b;
+    if (n == 1) {
+      const int slot = (int)out->leaf_idx.size();
+      out->leaf_idx.push_back(order[b]);
+      return ~(slot << 3);
+    }
+    // two median splits: up to four parts
+    int cut[5] = {b, b, b, b, e};
+    int m;
+    split(b, e, m);
+    int parts = 0;
+    int lo[4], hi[4];
+    const int halves[2][2] = {{b, m}, {m, e}};
+    for (int h = 0; h < 2; h++) {
+      const int hb = halves[h][0], he = halves[h][1];
+      if (he - hb >= 2) {
+        int mm;
+        split(hb, he, mm);
+        lo[parts] = hb;
+        hi[parts++] = mm;
+        lo[parts] = mm;
+        hi[parts++] = he;
+      } else if (he - hb == 1) {
+        lo[parts] = hb;
+        hi[parts++] = he;
+      }
+    }
+    (void)cut;
     const int me = (int)out->nodes.size();
     out->nodes.push_back(BvhNode{});
-    float4 s0, s1;
-    int32_t l0 = build(b, m, s0);
-    int32_t l1 = build(m, e, s1);
+    float4 cs[BVH_WIDTH];
+    int32_t cl[BVH_WIDTH];
+    for (int k = 0; k < BVH_WIDTH; k++) {
+      if (k < parts) {
+        cl[k] = build(lo[k], hi[k], cs[k]);
+      } else {
+        cl[k] = BVH_EMPTY;
+        cs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     BvhNode &N = out->nodes[me];
-    N.s0 = s0;
-    N.s1 = s1;
-    N.link0 = l0;
-    N.link1 = l1;
-    N.near0 = near_bound(s0);
-    N.near1 = near_bound(s1);
+    for (int k = 0; k < BVH_WIDTH; k++) {
+      N.s[k] = cs[k];
+      N.link[k] = cl[k];
+      N.near[k] = k < parts ? near_bound(cs[k]) : INFINITY;
+    }
     return me;
   }
 };
@@ -113,17 +146,17 @@ void bvh_build(const float *spheres, const float *radius, int n, BvhHost &out) {
   B.out = &out;
   out.leaf_idx.reserve(n);
   float4 root;
-  // node 0 is always the root; a scene that fits one leaf still gets a node
-  out.nodes.push_back(BvhNode{});
-  if (n <= BVH_LEAF_MAX) {
-    int32_t l = B.build(0, n, root);
-    out.nodes[0].s0 = root;
-    out.nodes[0].s1 = root;
-    out.nodes[0].link0 = l;
-    out.nodes[0].link1 = BVH_EMPTY;
-    out.nodes[0].near0 = out.nodes[0].near1 = -INFINITY;
+  // node 0 is always the root; a one-sphere scene still gets a node
+  if (n == 1) {
+    out.nodes.push_back(BvhNode{});
+    int32_t l = B.build(0, 1, root);
+    BvhNode &N = out.nodes[0];
+    for (int k = 0; k < BVH_WIDTH; k++) {
+      N.s[k] = root;
+      N.link[k] = k == 0 ? l : BVH_EMPTY;
+      N.near[k] = k == 0 ? -INFINITY : INFINITY;
+    }
   } else {
-    out.nodes.pop_back();
     int32_t l = B.build(0, n, root);
     (void)l; // == 0: the first node pushed
   }

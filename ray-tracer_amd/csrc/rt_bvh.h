@@ -13,18 +13,20 @@
 
 namespace rt {
 
-// One inner node holds the bounding spheres of its two children, so a visit
-// costs one 48-byte load.  link >= 0: index of the child node.  link < 0: leaf,
-// ~link = (first << 3) | (count - 1) into the leaf arrays (count <= 8).
+// One inner node holds the bounding spheres of up to four children, so a visit
+// costs one 96-byte load and the walk is half as deep as a binary tree's (the
+// walk is bound by the chain of dependent node loads and by per-visit overhead,
+// not by the bound tests).  link >= 0: index of the child node.  link < 0: leaf,
+// ~link = (slot << 3) into the leaf arrays (one sphere per leaf).
+constexpr int BVH_WIDTH = 4;
 struct BvhNode {
-  float4 s0, s1; // centre.xyz, radius (covers every member sphere entirely)
-  int32_t link0, link1;
-  float near0, near1; // |centre| - radius rounded down: no point of the child is
-                      // closer to the world origin than this
+  float4 s[BVH_WIDTH];      // centre.xyz, radius (covers every member sphere entirely)
+  int32_t link[BVH_WIDTH];  // BVH_EMPTY: no such child
+  float near[BVH_WIDTH];    // |centre| - radius rounded down: no point of the child
+                            // is closer to the world origin than this
 };
 constexpr int32_t BVH_EMPTY = 0x7fffffff;
-constexpr int BVH_LEAF_MAX = 1;
-constexpr int BVH_STACK = 40;
+constexpr int BVH_STACK = 48;
 
 struct BvhHost {
   std::vector<BvhNode> nodes;

@@ -510,47 +510,47 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
         float bound = ANY_HIT ? RT_INF : len_t;
         while (!done) {
           const BvhNode N = sc.bvh[node];
+          n_nodes += BVH_WIDTH;
           int next = -1;
-          n_nodes += 2;
-          // the child nearer to the world origin first: it tightens `bound`
-          const bool swap = N.near1 < N.near0;
+          float next_near = RT_INF;
 #pragma unroll
-          for (int cc = 0; cc < 2; cc++) {
-            const bool c = (cc != 0) != swap;
-            const float4 s = c ? N.s1 : N.s0;
-            const float near = c ? N.near1 : N.near0;
-            const int32_t link = c ? N.link1 : N.link0;
+          for (int c = 0; c < BVH_WIDTH; c++) {
+            const int32_t link = N.link[c];
             if (link == BVH_EMPTY ||
-                !bvh_touches(s, near, ox, oy, oz, dx, dy, dz, a, da, bound))
+                !bvh_touches(N.s[c], N.near[c], ox, oy, oz, dx, dy, dz, a, da, bound))
               continue;
             if (link >= 0) {
-              if (next < 0)
+              // keep the child nearest to the world origin for the next visit (it
+              // tightens `bound`), stack the others
+              int push = link;
+              if (N.near[c] < next_near) {
+                push = next;
                 next = link;
-              else if (sp < BVH_STACK)
-                stack[sp++] = link;
+                next_near = N.near[c];
+              }
+              if (push >= 0 && sp < BVH_STACK)
+                stack[sp++] = push;
             } else {
-              const int v = ~link, first = v >> 3, count = (v & 7) + 1;
-              n_leaf += count;
-              for (int k = 0; k < count; k++) {
-                const float4 g = sc.leaf_geo[first + k];
-                float Px, Py, Pz;
-                if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz,
-                                 Px, Py, Pz)) {
-                  const float len = length3(Px, Py, Pz);
-                  const int idx = sc.leaf_idx[first + k];
-                  // renderer.cpp:170 scans in index order with a strict '>':
-                  // the smallest |P| wins and, among equals, the lowest index
-                  if (len < RT_INF && (len < len_s || (len == len_s && idx < idx_s))) {
-                    len_s = len;
-                    idx_s = idx;
-                    sPx = Px;
-                    sPy = Py;
-                    sPz = Pz;
-                    if (ANY_HIT)
-                      done = true;
-                    else
-                      bound = fminf(bound, len);
-                  }
+              const int slot = (~link) >> 3;
+              n_leaf += 1;
+              const float4 g = sc.leaf_geo[slot];
+              float Px, Py, Pz;
+              if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py,
+                               Pz)) {
+                const float len = length3(Px, Py, Pz);
+                const int idx = sc.leaf_idx[slot];
+                // renderer.cpp:170 scans in index order with a strict '>':
+                // the smallest |P| wins and, among equals, the lowest index
+                if (len < RT_INF && (len < len_s || (len == len_s && idx < idx_s))) {
+                  len_s = len;
+                  idx_s = idx;
+                  sPx = Px;
+                  sPy = Py;
+                  sPz = Pz;
+                  if (ANY_HIT)
+                    done = true;
+                  else
+                    bound = fminf(bound, len);
                 }
               }
             }

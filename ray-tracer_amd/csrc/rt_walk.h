@@ -219,18 +219,17 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
     }
 
     if (state == BUSY) {
-      // ---- one node visit: both children's bounds (see bvh_touches) ----
+      // ---- one node visit: the bounds of its (up to four) children ----
       const BvhNode N = sc.bvh[node];
-      const bool t0 = N.link0 != BVH_EMPTY &&
-                      bvh_touches(N.s0, N.near0, ox, oy, oz, dx, dy, dz, a, da, bound);
-      const bool t1 = N.link1 != BVH_EMPTY &&
-                      bvh_touches(N.s1, N.near1, ox, oy, oz, dx, dy, dz, a, da, bound);
-      // touched leaves are parked (or, with four already parked, tested now)
+      int next = -1;
+      float next_near = RT_INF;
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const bool t = c ? t1 : t0;
-        const int32_t link = c ? N.link1 : N.link0;
+      for (int c = 0; c < BVH_WIDTH; c++) {
+        const int32_t link = N.link[c];
+        const bool t = link != BVH_EMPTY &&
+                       bvh_touches(N.s[c], N.near[c], ox, oy, oz, dx, dy, dz, a, da, bound);
         if (t && link < 0) {
+          // a touched leaf is parked (or, with four already parked, tested now)
           const int slot = (~link) >> 3;
           if (n_park < 4) {
             if (n_park == 0)
@@ -247,19 +246,21 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
             if (!ANY_HIT)
               bound = fminf(bound, len_s);
           }
+        } else if (t) {
+          // visit the child nearest to the world origin next (it tightens
+          // `bound`), stack the others
+          int push = link;
+          if (N.near[c] < next_near) {
+            push = next;
+            next = link;
+            next_near = N.near[c];
+          }
+          if (push >= 0 && sp < BVH_STACK)
+            stack[sp++] = push;
         }
       }
-      const bool in0 = t0 && N.link0 >= 0, in1 = t1 && N.link1 >= 0;
-      // descend into the child nearer to the world origin first: it tightens bound
-      const bool first1 = in1 && (!in0 || N.near1 < N.near0);
-      int next = -1;
-      if (in0 || in1) {
-        next = first1 ? N.link1 : N.link0;
-        if (in0 && in1 && sp < BVH_STACK)
-          stack[sp++] = first1 ? N.link0 : N.link1;
-      } else if (sp > 0) {
+      if (next < 0 && sp > 0)
         next = stack[--sp];
-      }
       if (next >= 0 && !(ANY_HIT && idx_s >= 0))
         node = next;
       else
