@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend for --gpus > 1; gloo stages the bands through "
+                         "host memory and exists to rehearse the multi-rank path on one GPU")
     ap.add_argument("--screen", choices=["auto", "off", "beam", "bvh"], default="auto",
                     help="work avoidance mode (rt_set_screen); off = plain every-ray-"
                          "every-sphere loop")
@@ -92,11 +95,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    n_dev = torch.cuda.device_count()
+    local_rank = local_rank % max(1, n_dev)   # a rehearsal may put several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     name = args.workload or default_workload()
     sc, w, h, depth = build_scene(name)
@@ -109,12 +118,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ds = rtamd.DeviceScene(sc)
     rtamd.set_screen(args.screen)
-    send, recv = plan.alloc_gather(dev)
+    send, recv = plan.alloc_gather(comm_dev)
     # A second frame buffer lets the gather of frame k overlap the render of
     # frame k+1 (the gather runs on the communicator's own stream).
     n_buf = 2 if world > 1 else 1
     fbs = [fb] + [plan.alloc_frame(dev) for _ in range(n_buf - 1)]
-    gath = [(send, recv)] + [plan.alloc_gather(dev) for _ in range(n_buf - 1)]
+    gath = [(send, recv)] + [plan.alloc_gather(comm_dev) for _ in range(n_buf - 1)]
     events = []     # (start, end) pairs around the device work of each timed frame
     pending = [None] * n_buf
 

@@ -52,7 +52,7 @@ class BandPlan:
             return None
         bands = fb.view(self.n_bands, self.band_bytes)
         mine = bands[self.rank::self.world]
-        send[:mine.shape[0]].copy_(mine)
+        send[:mine.shape[0]].copy_(mine)   # device -> host when send lives on the CPU (gloo)
         work = dist.gather(send, recv, dst=0, async_op=async_op)
         if async_op:
             return work
