@@ -311,3 +311,28 @@ def material_grid_scene(row: int, col: int, seed: int = 0x5EED) -> Scene:
     sc = grid_scene(row, col)
     sc.mat_sphere = seeded_materials(sc.s_size, seed)
     return sc
+
+
+def mesh_scene(nx: int, ny: int, grid: int = 10, seed: int = 0x5EED, materials: bool = True) -> Scene:
+    """The triangle-heavy configuration at any size: a displaced height field
+    over x in [-80,80], y in [-45,45], z in [-90,-60] cut into nx*ny quads
+    (2*nx*ny triangles; 1000 x 500 gives the 1 M-triangle scene), plus a
+    grid x grid block of the reference's unit spheres and its light.  Fixed seed."""
+    rng = np.random.RandomState(seed)
+    xs = np.linspace(-80, 80, nx + 1, dtype=np.float32)
+    ys = np.linspace(-45, 45, ny + 1, dtype=np.float32)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    Z = (-75 + 9 * np.sin(X * 0.11) * np.cos(Y * 0.17) +
+         rng.uniform(-6, 6, X.shape)).astype(np.float32)
+    P = np.stack([X, Y, Z], -1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t1 = np.concatenate([a, b, c], -1).reshape(-1, 9)
+    t2 = np.concatenate([a, c, d], -1).reshape(-1, 9)
+    tris = np.concatenate([t1, t2]).astype(np.float32)
+    tcol = rng.randint(40, 256, (len(tris), 3)).astype(np.uint8)
+    s, r, col = sphere_grid(grid, grid)
+    sc = Scene(tris, tcol, s, r, col, LIGHT.copy())
+    if materials:
+        sc.mat_sphere = seeded_materials(sc.s_size, seed)
+        sc.mat_tri = seeded_materials(sc.t_size, seed + 1)
+    return sc

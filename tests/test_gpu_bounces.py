@@ -128,3 +128,13 @@ def test_invalid_materials_rejected():
         rtamd.render(sc, 32, 32, max_depth=3)
     with pytest.raises(rtamd.RtError):
         rtamd.render(golden_scenes.mixed_scene(), 32, 32, max_depth=64)
+
+
+def test_triangle_mesh_configuration_reduced(oracle):
+    """The triangle-heavy configuration (height-field mesh + spheres, materials
+    on triangles too) at a size the oracle finishes: 4000 triangles, 256x144,
+    depth 1 and depth 4.  Triangles are looped by every ray."""
+    sc = rtamd.mesh_scene(50, 40)
+    assert sc.t_size == 4000
+    compare(sc, 256, 144, 1, oracle)
+    compare(sc, 256, 144, 4, oracle)

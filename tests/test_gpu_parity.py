@@ -273,3 +273,65 @@ def test_screen_never_drops_a_candidate(name, w, h):
           f"({kept / max(1, waves):.1f} per wave, {sc.s_size} spheres)")
     assert dropped_but_candidate == 0
     assert kept > 0
+
+
+def _wild_scene(seed, n):
+    """Spheres over six orders of magnitude in radius, clustered and scattered,
+    some nested, some touching, a few duplicated."""
+    rng = np.random.RandomState(seed)
+    c = np.concatenate([rng.normal(scale=30, size=(n // 2, 3)),
+                        rng.normal(scale=2, size=(n // 4, 3)) + [5, 5, -20],
+                        rng.uniform(-3000, 3000, size=(n - n // 2 - n // 4, 3))]).astype(np.float32)
+    r = np.exp(rng.uniform(np.log(1e-3), np.log(3e2), n)).astype(np.float32)
+    c[10], r[10] = c[11], r[11]            # duplicate
+    c[12], r[12] = c[13], r[13] * 0.5      # concentric
+    col = rng.randint(0, 256, (n, 3)).astype(np.uint8)
+    tris = rng.uniform(-50, 50, (6, 9)).astype(np.float32)
+    tcol = rng.randint(0, 256, (6, 3)).astype(np.uint8)
+    return rtamd.Scene(tris, tcol, c, r, col, np.array([[0, 40, 10]], np.float32))
+
+
+@pytest.mark.parametrize("seed,n", [(101, 3000), (102, 517)])
+def test_hierarchy_walk_on_wild_scenes(oracle, seed, n):
+    """Bulk queries through the sphere hierarchy: random rays, then rays that
+    start exactly on the surfaces they hit (what shadow and bounce rays do:
+    self-hits are kept out only by the reference's epsilons, maths.cpp:147-152)."""
+    sc = _wild_scene(seed, n)
+    rng = np.random.RandomState(seed + 1)
+    m = 60000
+    o = rng.normal(scale=60, size=(m, 3)).astype(np.float32)
+    tgt = sc.spheres[rng.randint(0, n, m)] + (rng.normal(size=(m, 3)) * sc.radius[rng.randint(0, n, m), None]).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    d[: m // 2] /= np.linalg.norm(d[: m // 2], axis=1, keepdims=True)
+    with rtamd.DeviceScene(sc) as ds:
+        k1, i1, p1 = ds.check_intersection(o, d)
+        k0, i0, p0 = oracle.check_intersection(sc, o, d)
+        assert np.array_equal(k0, k1) and np.array_equal(i0, i1)
+        hit = k0 != 0
+        assert hit.mean() > 0.3
+        assert np.array_equal(p0.view(np.uint32)[hit], p1.view(np.uint32)[hit])
+        # second generation: from the hit points, towards the light and at random
+        o2 = np.concatenate([p0[hit], p0[hit]])
+        to_light = sc.lights[0] - p0[hit]
+        to_light /= np.linalg.norm(to_light, axis=1, keepdims=True)
+        d2 = np.concatenate([to_light, rng.normal(size=to_light.shape)]).astype(np.float32)
+        k3, i3, p3 = ds.check_intersection(o2, d2)
+    k2, i2, p2 = oracle.check_intersection(sc, o2, d2)
+    assert np.array_equal(k2, k3) and np.array_equal(i2, i3)
+    h2 = k2 != 0
+    assert np.array_equal(p2.view(np.uint32)[h2], p3.view(np.uint32)[h2])
+
+
+def test_wild_scene_frames_in_every_mode(oracle):
+    sc = _wild_scene(103, 800)
+    cam = rtamd.default_camera(100)
+    cam.origin[0], cam.origin[1], cam.origin[2] = 3.0, -2.0, 60.0
+    fo, io, no = oracle.render(sc, 480, 300, cam=cam)
+    for mode in ("off", "beam", "bvh"):
+        try:
+            rtamd.set_screen(mode)
+            fb, ids, n = rtamd.render(sc, 480, 300, cam=cam)
+        finally:
+            rtamd.set_screen("auto")
+        assert_frame_parity(fb, ids, fo, io, f"wild scene, mode {mode}")
+        assert n == no
