@@ -257,9 +257,8 @@ struct Beam {
 
 #define RT_SCREEN_EPS 1.52587890625e-05f /* 2^-16 */
 
-// delta = D * delta_scale: 2^-20 when every line passes through the apex up to
-// the rounding of its direction, slightly more than 1 when the apex is merely a
-// point near the ray origins (then a line misses it by at most |o - X|).
+// delta = D * delta_scale with delta_scale = 2^-20: every line passes through the
+// apex up to the rounding of its direction.
 __device__ __forceinline__ Beam make_beam(bool lv, float a, float dx, float dy,
                                           float dz, float Xx, float Xy, float Xz,
                                           float Dk, float delta_scale) {
@@ -314,13 +313,11 @@ __device__ __forceinline__ bool beam_keeps(const Beam &B, float4 g) {
 // ANY_HIT : only "is anything hit" is wanted (shadow rays, renderer.cpp:119);
 //           the loop may stop as soon as every live lane has a hit, which
 //           cannot change the answer.
-//           3 = no bundle at all: each lane walks the bounding-sphere hierarchy
-//           for its own ray (bvh_touches below).
-// BEAM    : 0 = no screen.  1 = the wave's rays share the apex (Xx,Xy,Xz) (the
-//           eye, or the light a shadow ray aims at); Dk is the lane's distance
-//           from its ray origin to the apex.  2 = bounce rays: no common point,
-//           the apex is the mean ray origin and every line is within |o - X| of
-//           the parallel line through it.
+// BEAM    : RT_BEAM_NONE = every ray against every sphere.  RT_BEAM_APEX = the
+//           wave's rays share the apex (Xx,Xy,Xz) (the eye, or the light a shadow
+//           ray aims at) and are screened as a bundle; Dk is the lane's distance
+//           from its ray origin to the apex.  RT_ACCEL_BVH = no bundle: each lane
+//           walks the bounding-sphere hierarchy for its own ray (bvh_touches).
 //
 // Nearest is by |P| from the WORLD origin with strict '>' (lowest index wins in
 // a class); between classes a triangle wins ties ('<=', renderer.cpp:181).  A
@@ -340,7 +337,6 @@ struct ScreenStats { // filled only by the verification build of the kernels
 
 #define RT_BEAM_NONE 0
 #define RT_BEAM_APEX 1
-#define RT_BEAM_MEAN 2
 #define RT_ACCEL_BVH 3
 
 // Can the line {o + t d} touch any sphere inside the bounding sphere s?  Must
@@ -417,22 +413,11 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   bool seek = live && !(ANY_HIT && idx_t >= 0);
 
   bool screened = false;
-  if (BEAM == RT_BEAM_APEX || BEAM == RT_BEAM_MEAN) {
+  if (BEAM == RT_BEAM_APEX) {
     // rays with a == 0 or NaN never yield an accepted sphere hit (see above)
     const bool lv = seek && (a > 0.f);
     if (__any(lv)) {
-      float dscale = 9.5367431640625e-07f; // 2^-20
-      if (BEAM == RT_BEAM_MEAN) {
-        const float inv_n = 1.0f / (float)__builtin_popcountll(__ballot(lv));
-        Xx = uniform(wave_sum(lv ? ox : 0.f) * inv_n);
-        Xy = uniform(wave_sum(lv ? oy : 0.f) * inv_n);
-        Xz = uniform(wave_sum(lv ? oz : 0.f) * inv_n);
-        float ex = ox - Xx, ey = oy - Xy, ez = oz - Xz;
-        // |o - X|, rounded up: one-sided by (1+2^-18) and an absolute 2^-30
-        Dk = fmaf(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))), 1.000003814697265625f,
-                  9.313225746154785e-10f);
-        dscale = 1.000003814697265625f;
-      }
+      const float dscale = 9.5367431640625e-07f; // 2^-20
       const Beam B = make_beam(lv, a, dx, dy, dz, Xx, Xy, Xz, Dk, dscale);
       if (B.narrow) {
         screened = true;

@@ -6,9 +6,13 @@
 // Kernels
 //   k_prep_scene      once per scene: flat arrays -> sphere/triangle records
 //   k_prep_eye        once per eye position: eye-relative sphere/triangle terms
+//   k_gather_leaves   once per scene: sphere records in hierarchy leaf order
 //   k_render          one lane per pixel, one 8x8 pixel tile per wave:
 //                     ray generation, nearest hit, Phong + shadow rays, pixel
-//                     write (renderer.cpp:28-140)
+//                     write (renderer.cpp:28-140), first-bounce rays queued
+//   k_walk, k_shade   one bounce level as three launches (rt_walk.h)
+//   k_bounce          one bounce level in one launch (no hierarchy / self-check)
+//   k_compose         adds the bounce hits' integer light to the framebuffer
 //   k_check           one lane per caller-supplied ray (renderer.cpp:145-193)
 #include "rt_device.h"
 #include "rt_kernels.h"
