@@ -6,7 +6,8 @@
 // (main.cpp:98-101).  Additions, all optional: -w/-H frame size (default the
 // reference's 2560x1440, renderer.hpp:10-11), -depth D, -o <ppm path>,
 // -keep-spheres (use the file's spheres), -phantoms (reference-compatible blank
-// lines).  There is no viewer here: without -n the frame is rendered and dropped.
+// lines), -repeat N (call gpu_render N times and report each; the first call of
+// a process also pays for the HIP context and code-object load).  There is no viewer here: without -n the frame is rendered and dropped.
 #include "../../include/rt_amd.h"
 #include "../../include/rt_host.h"
 
@@ -48,6 +49,7 @@ int main(int argc, char **argv) {
   const int h = opt(argc, argv, "-H") ? atoi(opt(argc, argv, "-H")) : 1440;
   const int depth = opt(argc, argv, "-depth") ? atoi(opt(argc, argv, "-depth")) : 1;
   const char *out = opt(argc, argv, "-o") ? opt(argc, argv, "-o") : "image.ppm";
+  const int repeat = opt(argc, argv, "-repeat") ? atoi(opt(argc, argv, "-repeat")) : 1;
 
   rt_host_scene hs;
   int bad = 0;
@@ -79,17 +81,20 @@ int main(int argc, char **argv) {
 
   std::vector<uint8_t> fb((size_t)4 * w * h);
   uint64_t rays = 0;
-  auto t0 = std::chrono::steady_clock::now();
-  rc = gpu_render_ids(&s, &cam, fb.data(), nullptr, &rays, w, h, depth);
-  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (rc != RT_OK) {
-    fprintf(stderr, "gpu_render failed (%d): %s\n", rc, rt_last_error());
-    rt_host_free_scene(&hs);
-    return 1;
+  for (int it = 0; it < (repeat > 0 ? repeat : 1); it++) {
+    auto t0 = std::chrono::steady_clock::now();
+    rc = gpu_render_ids(&s, &cam, fb.data(), nullptr, &rays, w, h, depth);
+    double ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != RT_OK) {
+      fprintf(stderr, "gpu_render failed (%d): %s\n", rc, rt_last_error());
+      rt_host_free_scene(&hs);
+      return 1;
+    }
+    fprintf(stderr, "%dx%d, %d triangles, %d spheres, %d lights, depth %d: %llu rays in %.1f ms "
+                    "(upload + render + copy-back)\n",
+            w, h, s.t_size, s.s_size, s.l_size, depth, (unsigned long long)rays, ms);
   }
-  fprintf(stderr, "%dx%d, %d triangles, %d spheres, %d lights, depth %d: %llu rays in %.1f ms "
-                  "(upload + render + copy-back)\n",
-          w, h, s.t_size, s.s_size, s.l_size, depth, (unsigned long long)rays, ms);
   if (flag(argc, argv, "-n") && rt_host_write_ppm(out, fb.data(), w, h) != 0) { // main.cpp:155-173
     fprintf(stderr, "cannot write %s\n", out);
     rt_host_free_scene(&hs);
