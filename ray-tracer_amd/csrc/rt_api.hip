@@ -70,19 +70,24 @@ struct rt_scene {
   DevBuf<float4> leaf_geo;
   DevBuf<int32_t> leaf_idx;
   bool has_bvh = false;
+  DevBuf<rt::TriNode> tbvh;
+  DevBuf<rt::TriRec> tleaf;
+  DevBuf<int32_t> tleaf_idx, tloose;
+  bool has_tbvh = false;
   bool has_mat_tri = false, has_mat_sph = false;
   bool eye_valid = false;
   float eye[3] = {0, 0, 0};
   // bounce machinery, allocated on the first max_depth > 1 render
   DevBuf<float4> queue[2];
   // control words.  A "row" is one counter per queue segment (QUEUE_SEGMENTS x
-  // CTL_WORDS uint32).  Per level: rows {queue length, walk cursor, hit count} then
-  // per light {shadow items, shadow cursor}; the very last word is the overflow flag
+  // CTL_WORDS uint32).  Per level: rows {queue length, sphere-walk cursor,
+  // triangle-walk cursor}, then per group of lights {shadow items, sphere-walk
+  // cursor, triangle-walk cursor}; the very last word is the overflow flag
   DevBuf<uint32_t> counts;
   int ctl_rows = 0; // rows per level
   DevBuf<unsigned long long> extra; // per pixel, 3 x 21 bits
-  DevBuf<float4> hit_rec, shadow_items;
-  DevBuf<int32_t> hit_idx;
+  DevBuf<float4> hit_rec, tri_hit_rec, shadow_items;
+  DevBuf<int32_t> hit_idx, tri_hit_idx;
   size_t queue_capacity = 0, extra_pixels = 0;
 
   rt::SceneDev dev() const {
@@ -103,6 +108,13 @@ struct rt_scene {
     d.bvh = use_bvh ? bvh.p : nullptr;
     d.leaf_geo = use_bvh ? leaf_geo.p : nullptr;
     d.leaf_idx = use_bvh ? leaf_idx.p : nullptr;
+    const bool use_tbvh = has_tbvh && g_screen != 0;
+    d.tbvh = use_tbvh ? tbvh.p : nullptr;
+    d.tleaf = use_tbvh ? tleaf.p : nullptr;
+    d.tleaf_idx = use_tbvh ? tleaf_idx.p : nullptr;
+    d.tloose = use_tbvh ? tloose.p : nullptr;
+    d.n_tleaf = use_tbvh ? (int)tleaf_idx.n : 0;
+    d.n_tloose = use_tbvh ? (int)tloose.n : 0;
     return d;
   }
 };
@@ -150,6 +162,10 @@ int upload(DevBuf<T> &dst, const void *src, size_t count) {
     HIP_TRY(hipMemcpy(dst.p, src, count * sizeof(T), hipMemcpyHostToDevice));
   return RT_OK;
 }
+
+// Fewer triangles than this are looped over by every ray (renderer.cpp:156-166
+// as written); from here on the rays walk a hierarchy (rt_tribvh.h).
+constexpr int kTriTreeMin = 16;
 
 int scene_build(rt_scene *S, const scene_desc *s) {
   HIP_TRY(hipGetDevice(&S->device));
@@ -225,6 +241,21 @@ int scene_build(rt_scene *S, const scene_desc *s) {
                                        (int)H.leaf_idx.size(), nullptr));
     }
   }
+  // triangle hierarchy, once there are enough triangles for it to pay
+  if (s->t_size >= kTriTreeMin) {
+    rt::TriBvhHost H;
+    rt::tri_bvh_build(s->tris, s->t_size, H);
+    S->has_tbvh = H.valid && !H.nodes.empty();
+    if (S->has_tbvh) {
+      if ((rc = upload(S->tbvh, H.nodes.data(), H.nodes.size())) ||
+          (rc = upload(S->tleaf_idx, H.leaf_idx.data(), H.leaf_idx.size())) ||
+          (rc = upload(S->tloose, H.loose.data(), H.loose.size())))
+        return rc;
+      HIP_TRY(S->tleaf.alloc(H.leaf_idx.size()));
+      HIP_TRY(rt::launch_gather_tri_leaves(S->tri.p, S->tleaf_idx.p, S->tleaf.p,
+                                           (int)H.leaf_idx.size(), nullptr));
+    }
+  }
   HIP_TRY(hipStreamSynchronize(nullptr)); // staging buffers die here
   S->eye_valid = false;
   return RT_OK;
@@ -267,11 +298,15 @@ int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels)
       HIP_TRY(S->queue[q].alloc(2 * want));
     HIP_TRY(S->hit_rec.alloc(want));
     HIP_TRY(S->hit_idx.alloc(want));
+    if (S->has_tbvh) {
+      HIP_TRY(S->tri_hit_rec.alloc(want));
+      HIP_TRY(S->tri_hit_idx.alloc(want));
+    }
     HIP_TRY(S->shadow_items.alloc(2 * want * kLightGroup));
     S->queue_capacity = want;
   }
   if (!S->counts.p) {
-    S->ctl_rows = 2 + 2 * ((S->l_size + kLightGroup - 1) / kLightGroup + 1);
+    S->ctl_rows = 3 + 3 * ((S->l_size + kLightGroup - 1) / kLightGroup + 1);
     HIP_TRY(S->counts.alloc((size_t)kLevels * S->ctl_rows * kRowWords + 1));
   }
   if (S->extra_pixels < frame_pixels) {
@@ -431,7 +466,8 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
     // With a sphere hierarchy each level runs as walk / shade / shadow-walk
     // launches with dynamic ray fetch (rt_walk.h); otherwise, or in the
     // self-checking build, as one k_bounce launch per level.
-    const bool stream_levels = sd.bvh != nullptr && !dev_verify;
+    const bool stream_levels = (sd.bvh != nullptr || sd.tbvh != nullptr) && !dev_verify;
+    const bool tri_walks = sd.tbvh != nullptr;
     for (int level = 2; level <= fr->max_depth; level++) {
       bd.in = queue_for_level(S, level);
       bd.out = queue_for_level(S, level + 1);
@@ -440,21 +476,32 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
                                   (unsigned long long *)dev_verify, kBounceBlocks, st));
         continue;
       }
-      rt::HitList hl;
+      rt::HitList hl, tl;
       hl.rec = S->hit_rec.p;
       hl.idx = S->hit_idx.p;
+      tl.rec = tri_walks ? S->tri_hit_rec.p : nullptr;
+      tl.idx = tri_walks ? S->tri_hit_idx.p : nullptr;
       rt::WalkArgs wa;
       memset(&wa, 0, sizeof wa);
       wa.in = bd.in;
+      wa.extra = S->extra.p;
+      // each ray is counted once, by the first walk it goes through
+      if (tri_walks) {
+        wa.cursor = ctl(S, level, 2);
+        wa.hits = tl;
+        wa.ray_count = dev_ray_count;
+        HIP_TRY(rt::launch_walk(sd, wa, false, true, kBounceBlocks, st));
+        wa.prior = tl;
+      }
       wa.cursor = ctl(S, level, 1);
       wa.hits = hl;
-      wa.extra = S->extra.p;
-      wa.ray_count = dev_ray_count;
-      HIP_TRY(rt::launch_walk(sd, wa, false, kBounceBlocks, st));
+      wa.ray_count = tri_walks ? nullptr : dev_ray_count;
+      HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
       rt::ShadeArgs sa;
       memset(&sa, 0, sizeof sa);
       sa.rays = bd.in;
       sa.hits = hl;
+      sa.tri_hits = tl;
       sa.max_depth = fr->max_depth;
       sa.next = bd.out;
       sa.ray_count = dev_ray_count;
@@ -464,7 +511,7 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
         sa.light_end = S->l_size < (g + 1) * kLightGroup ? S->l_size : (g + 1) * kLightGroup;
         sa.spawn = g == 0;
         sa.shadow.items = S->shadow_items.p;
-        sa.shadow.count = ctl(S, level, 2 + 2 * g);
+        sa.shadow.count = ctl(S, level, 3 + 3 * g);
         sa.shadow.seg_capacity = bd.in.seg_capacity * kLightGroup;
         sa.shadow.overflow = overflow_flag(S);
         HIP_TRY(rt::launch_shade(sd, sa, kBounceBlocks, st));
@@ -472,10 +519,15 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
           rt::WalkArgs ws;
           memset(&ws, 0, sizeof ws);
           ws.in = sa.shadow;
-          ws.cursor = ctl(S, level, 3 + 2 * g);
           ws.extra = S->extra.p;
-          ws.ray_count = dev_ray_count;
-          HIP_TRY(rt::launch_walk(sd, ws, true, kBounceBlocks, st));
+          if (tri_walks) {
+            ws.cursor = ctl(S, level, 5 + 3 * g);
+            ws.ray_count = dev_ray_count;
+            HIP_TRY(rt::launch_walk(sd, ws, true, true, kBounceBlocks, st));
+          }
+          ws.cursor = ctl(S, level, 4 + 3 * g);
+          ws.ray_count = tri_walks ? nullptr : dev_ray_count;
+          HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, st));
         }
       }
     }

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "rt_bvh.h"
+#include "rt_tribvh.h"
 
 namespace rt {
 
@@ -50,6 +51,12 @@ struct SceneDev {
   const BvhNode *bvh;
   const float4 *leaf_geo;    // sph_geo gathered into leaf order
   const int32_t *leaf_idx;   // original sphere index of each leaf slot
+  // hierarchy over the triangles (rt_tribvh.h); tbvh == nullptr: none, loop
+  const TriNode *tbvh;
+  const TriRec *tleaf;       // triangle records gathered into leaf order
+  const int32_t *tleaf_idx;  // original triangle index of each leaf slot
+  const int32_t *tloose;     // triangles outside the hierarchy, tested by every ray
+  int n_tleaf, n_tloose;
 };
 
 struct CameraDev {
@@ -377,6 +384,166 @@ __device__ __forceinline__ bool bvh_touches(float4 s, float near, float ox, floa
   return !(lhs > rhs) && !behind && !far;
 }
 
+// ---- the triangle hierarchy (rt_tribvh.h) ------------------------------------------
+// Can the ray hit a triangle of the child (s, n, spread)?  Must say yes whenever
+// the float test of maths.cpp:64-119 can report a hit for a member triangle i.
+// Such a hit has P~ = o + t~ d (float) passing the three inside tests with
+// t~ >= 0.  Write Q~ = P~ - 2 (N_i.o) N_i.  Then
+//   - Q~ is within e1 = 7u|o| + 2u(|M| + R) of the line from the mirrored origin
+//     o'_i = o - 2 (N_i.o) N_i along d (rounding of P~, maths.cpp:83-87);
+//   - Q~ projects along N_i into the triangle grown by at most
+//     11u * 64 * (2|o| + diam): each inside test is a float evaluation of
+//     (N x e_k).(P~ - p_k) with error <= 10u |e_k||P~ - p_k| (maths.cpp:92-116),
+//     and the builder only admits corners no sharper than a growth factor of 64;
+//   - N_i.(Q~ - p1) = N_i.o + t~ (N_i.d) - N_i.p1 deviates from 0 by at most
+//     lam = 8u (1 + |d| / |nd|) (|o| + |p1|): 4u from the sums of maths.cpp:77-78,
+//     3u |d| / |nd| from the rounding of nd = N.d (maths.cpp:69), 1u from the
+//     division; |nd| >= max(|n.d| - spread |d|, 0.99e-4) by the parallel test
+//     (maths.cpp:72); plus the builder's allowance for corners off the plane,
+//     which is inside R.
+// So Q~ lies within R + lam + 2^-13 (|o| + R) + e1 of the centre, and o'_i within
+// |o| (K - 2^-12) of the mean mirrored origin q = o - 2 (n.o) n (K = n.w).  With
+// |o| + |p1| <= 2|o| + |M| + R =: S,
+//   Rtot = R (1 + 2^-12) + |o| K + 2^-16 |M| + 2^-21 S (1 + |d| / ndmin)
+// bounds the distance from the centre to the line {q + t d} for every possible
+// hit, t~ |d|^2 <= (C - q).d + Rtot |d| (so a child entirely behind q cannot be
+// hit: maths.cpp:80 rejects t < 0), and |P~| >= |C + (o - q)| - Rtot.  NaN or inf
+// anywhere answers yes.  `ol` >= |o|, `da` >= |d|.
+__device__ __forceinline__ bool tri_touches(float4 s, float4 n, float spread, float ox,
+                                            float oy, float oz, float dx, float dy, float dz,
+                                            float a, float da, float ol, float bound,
+                                            float &near_out) {
+  const float no2 = 2.0f * fmaf(n.z, oz, fmaf(n.y, oy, n.x * ox));
+  const float qx = fmaf(-no2, n.x, ox), qy = fmaf(-no2, n.y, oy), qz = fmaf(-no2, n.z, oz);
+  const float Mx = s.x - qx, My = s.y - qy, Mz = s.z - qz;
+  const float m2 = fmaf(Mz, Mz, fmaf(My, My, Mx * Mx));
+  const float md = fmaf(dz, Mz, fmaf(dy, My, dx * Mx));
+  const float mlen = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
+  const float nbd = fabsf(fmaf(n.z, dz, fmaf(n.y, dy, n.x * dx)));
+  const float ndmin = fmaxf(fmaf(-spread, da, nbd) * 0.999999f, 9.9e-5f);
+  const float S = fmaf(2.0f, ol, mlen + s.w);
+  const float lam = (S * 4.76837158203125e-07f) *
+                    fmaf(da * 1.00001f, __builtin_amdgcn_rcpf(ndmin), 1.0f); // 2^-21
+  const float Rtot = fmaf(s.w, 1.000245f, fmaf(ol, n.w, fmaf(mlen, 1.6e-5f, lam)));
+  const float lhs = fmaf(-md, md, (a * m2) * 0.99999809265136719f);
+  const float rhs = (a * Rtot) * (Rtot * 1.000001f);
+  const bool behind = fmaf(da, Rtot * 1.0001f, md) < 0.f;
+  const float fx = Mx + ox, fy = My + oy, fz = Mz + oz; // C + (o - q)
+  const float flen = __builtin_amdgcn_sqrtf(fmaf(fz, fz, fmaf(fy, fy, fx * fx)));
+  near_out = fmaf(flen, 0.999998f, -(Rtot * 1.000002f));
+  const bool far = near_out > bound;
+  return !(lhs > rhs) && !behind && !far;
+}
+
+// One exact triangle test (maths.cpp:64-119) folded into the running nearest
+// triangle hit: smallest |P|, lowest index on ties, the order-free form of
+// renderer.cpp:156-166.  Returns true when the hit was accepted.
+__device__ __forceinline__ bool tri_fold(const TriRec &T, int idx, float ox, float oy, float oz,
+                                         float dx, float dy, float dz, float &len_t, int &idx_t,
+                                         float &tPx, float &tPy, float &tPz) {
+  const float no = dot3(T.n_d.x, T.n_d.y, T.n_d.z, ox, oy, oz); // maths.cpp:78
+  float Px, Py, Pz;
+  if (!triangle_test(T, no, ox, oy, oz, dx, dy, dz, Px, Py, Pz))
+    return false;
+  const float len = length3(Px, Py, Pz);
+  if (len < RT_INF && (len < len_t || (len == len_t && idx < idx_t))) {
+    len_t = len;
+    idx_t = idx;
+    tPx = Px;
+    tPy = Py;
+    tPz = Pz;
+    return true;
+  }
+  return false;
+}
+
+// Per-ray constants of the triangle walk.  `usable` false: the ray's numbers
+// are outside the range the bounds were derived for and every triangle must
+// be tested; `possible` false: no triangle can be reported at all (d = 0 gives
+// nd = 0, a NaN in d or a non-finite origin makes |P| NaN or inf, and
+// renderer.cpp:159 never accepts those).
+struct TriWalkRay {
+  float a, da, ol;
+  bool possible, usable;
+};
+__device__ __forceinline__ TriWalkRay tri_walk_ray(float ox, float oy, float oz, float dx,
+                                                   float dy, float dz) {
+  TriWalkRay r;
+  r.a = dot3(dx, dy, dz, dx, dy, dz);
+  const float o2 = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+  r.da = __builtin_amdgcn_sqrtf(r.a) * 1.001f;
+  r.ol = __builtin_amdgcn_sqrtf(o2) * 1.001f + 1e-30f;
+  r.possible = r.a > 0.f && o2 < RT_INF;
+  r.usable = r.a > 9.094947e-13f && r.a < 1.0995116e12f && o2 < 1e36f;
+  return r;
+}
+
+// Every triangle for one lane's ray through the hierarchy (same result as the
+// loop of renderer.cpp:156-166).
+template <bool ANY_HIT>
+__device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, float oy, float oz,
+                                               float dx, float dy, float dz, float &len_t,
+                                               int &idx_t, float &tPx, float &tPy, float &tPz) {
+  const TriWalkRay r = tri_walk_ray(ox, oy, oz, dx, dy, dz);
+  if (!r.possible)
+    return;
+  for (int k = 0; k < sc.n_tloose; k++) {
+    const int i = sc.tloose[k];
+    if (tri_fold(sc.tri[i], i, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz) && ANY_HIT)
+      return;
+  }
+  if (sc.n_tleaf == 0)
+    return;
+  if (!r.usable) {
+    for (int slot = 0; slot < sc.n_tleaf; slot++)
+      if (tri_fold(sc.tleaf[slot], sc.tleaf_idx[slot], ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx,
+                   tPy, tPz) &&
+          ANY_HIT)
+        return;
+    return;
+  }
+  int stack[BVH_STACK];
+  int sp = 0, node = 0;
+  float bound = ANY_HIT ? RT_INF : len_t;
+  while (true) {
+    const TriNode N = sc.tbvh[node];
+    int next = -1;
+    float next_near = RT_INF;
+#pragma unroll
+    for (int c = 0; c < BVH_WIDTH; c++) {
+      const int32_t link = N.link[c];
+      float near;
+      if (link == BVH_EMPTY || !tri_touches(N.s[c], N.n[c], N.spread[c], ox, oy, oz, dx, dy, dz,
+                                            r.a, r.da, r.ol, bound, near))
+        continue;
+      if (link >= 0) {
+        int push = link;
+        if (near < next_near) {
+          push = next;
+          next = link;
+          next_near = near;
+        }
+        if (push >= 0 && sp < BVH_STACK)
+          stack[sp++] = push;
+      } else {
+        const int slot = (~link) >> 3;
+        if (tri_fold(sc.tleaf[slot], sc.tleaf_idx[slot], ox, oy, oz, dx, dy, dz, len_t, idx_t,
+                     tPx, tPy, tPz)) {
+          if (ANY_HIT)
+            return;
+          bound = fminf(bound, len_t);
+        }
+      }
+    }
+    if (next >= 0)
+      node = next;
+    else if (sp > 0)
+      node = stack[--sp];
+    else
+      return;
+  }
+}
+
 template <bool FROM_EYE, bool ANY_HIT, int BEAM, bool VERIFY = false>
 __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                                      float oy, float oz, float dx, float dy,
@@ -388,23 +555,28 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
 
   // ---- triangles, renderer.cpp:156-166 ----
-  for (int i = 0; i < sc.t_size; i++) {
-    const TriRec &T = sc.tri[i];
-    float no = FROM_EYE ? T.p1_no.w
-                        : dot3(T.n_d.x, T.n_d.y, T.n_d.z, ox, oy, oz);
-    float Px, Py, Pz;
-    if (live && triangle_test(T, no, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
-      float len = length3(Px, Py, Pz);
-      if (len_t > len) {
-        len_t = len;
-        idx_t = i;
-        tPx = Px;
-        tPy = Py;
-        tPz = Pz;
+  if (sc.tbvh != nullptr) {
+    if (live)
+      walk_triangles<ANY_HIT>(sc, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
+  } else {
+    for (int i = 0; i < sc.t_size; i++) {
+      const TriRec &T = sc.tri[i];
+      float no = FROM_EYE ? T.p1_no.w
+                          : dot3(T.n_d.x, T.n_d.y, T.n_d.z, ox, oy, oz);
+      float Px, Py, Pz;
+      if (live && triangle_test(T, no, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
+        float len = length3(Px, Py, Pz);
+        if (len_t > len) {
+          len_t = len;
+          idx_t = i;
+          tPx = Px;
+          tPy = Py;
+          tPz = Pz;
+        }
       }
+      if (ANY_HIT && !__any(live && idx_t < 0))
+        break;
     }
-    if (ANY_HIT && !__any(live && idx_t < 0))
-      break;
   }
 
   // ---- spheres, renderer.cpp:168-177 ----

@@ -73,6 +73,7 @@ struct WalkArgs {
   RayQueue in;        // items to walk: (origin, tagA bits), (direction, tagB bits)
   uint32_t *cursor;   // cursor[s * CTL_WORDS]: next item of segment s to hand out
   HitList hits;       // nearest-hit walks: where hits go
+  HitList prior;      // sphere nearest-hit walks: the rays' triangle hits, or null
   unsigned long long *extra; // shadow walks: tagA = pixel, tagB = packed integer
                              // light, added to the pixel if unoccluded
   uint64_t *ray_count;
@@ -81,6 +82,7 @@ struct WalkArgs {
 struct ShadeArgs {
   RayQueue rays;     // the level's rays
   HitList hits;      // their nearest sphere hits (k_walk)
+  HitList tri_hits;  // their nearest triangle hits (k_walk over the triangle hierarchy)
   int light_begin, light_end; // lights evaluated in this launch
   int spawn;         // also queue the next level's rays
   int max_depth;
@@ -114,13 +116,15 @@ hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
 hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
                          uint64_t *ray_count, unsigned long long *verify_stats,
                          int blocks, hipStream_t st);
-hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, int blocks,
-                       hipStream_t st);
+hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, bool triangles,
+                       int blocks, hipStream_t st);
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st);
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st);
 hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
                                 float4 *leaf_geo, int n, hipStream_t st);
+hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriRec *leaf,
+                                    int n, hipStream_t st);
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);
 
 } // namespace rt

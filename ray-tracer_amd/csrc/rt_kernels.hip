@@ -573,12 +573,18 @@ hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
   return hipGetLastError();
 }
 
-hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, int blocks,
-                       hipStream_t st) {
-  if (any_hit)
-    hipLaunchKernelGGL((k_walk<true>), dim3(blocks), dim3(256), 0, st, sc, w);
+hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, bool triangles,
+                       int blocks, hipStream_t st) {
+  if (triangles && sc.tbvh == nullptr)
+    return hipErrorInvalidValue;
+  if (any_hit && triangles)
+    hipLaunchKernelGGL((k_walk<true, true>), dim3(blocks), dim3(256), 0, st, sc, w);
+  else if (any_hit)
+    hipLaunchKernelGGL((k_walk<true, false>), dim3(blocks), dim3(256), 0, st, sc, w);
+  else if (triangles)
+    hipLaunchKernelGGL((k_walk<false, true>), dim3(blocks), dim3(256), 0, st, sc, w);
   else
-    hipLaunchKernelGGL((k_walk<false>), dim3(blocks), dim3(256), 0, st, sc, w);
+    hipLaunchKernelGGL((k_walk<false, false>), dim3(blocks), dim3(256), 0, st, sc, w);
   return hipGetLastError();
 }
 
@@ -610,6 +616,22 @@ __global__ void k_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n)
     leaf_geo[i] = sph_geo[leaf_idx[i]];
+}
+
+__global__ void k_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriRec *leaf,
+                                    int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    leaf[i] = tri[leaf_idx[i]];
+}
+
+hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriRec *leaf,
+                                    int n, hipStream_t st) {
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(k_gather_tri_leaves, dim3((n + 255) / 256), dim3(256), 0, st, tri, leaf_idx,
+                     leaf, n);
+  return hipGetLastError();
 }
 
 hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,

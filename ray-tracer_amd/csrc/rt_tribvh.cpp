@@ -1,0 +1,285 @@
+// rt_tribvh.cpp — host-side construction of the triangle hierarchy (rt_tribvh.h).
+//
+// All bounds are formed in double from the float scene data and rounded
+// outwards.  The per-triangle unit normal is evaluated in float by the very
+// operations of maths.cpp:39-52 (this file is compiled without contraction), so
+// it is the normal the device tests with; the allowances below do not depend on
+// that being bit-exact.
+#include "rt_tribvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace rt {
+namespace {
+
+float round_up(double x) {
+  float f = (float)x;
+  if ((double)f < x)
+    f = std::nextafter(f, INFINITY);
+  return f;
+}
+
+// maths.cpp:39-52 + 27-37 in float
+bool float_normal(const float *p1, const float *p2, const float *p3, float N[3]) {
+  float ax = p2[0] - p1[0], ay = p2[1] - p1[1], az = p2[2] - p1[2];
+  float bx = p3[0] - p1[0], by = p3[1] - p1[1], bz = p3[2] - p1[2];
+  float nx = ay * bz - az * by;
+  float ny = az * bx - ax * bz;
+  float nz = ax * by - ay * bx;
+  float l = sqrtf(nx * nx + ny * ny + nz * nz);
+  if (l != 0.0f) {
+    nx /= l;
+    ny /= l;
+    nz /= l;
+  }
+  N[0] = nx;
+  N[1] = ny;
+  N[2] = nz;
+  return std::isfinite(nx) && std::isfinite(ny) && std::isfinite(nz) &&
+         !(nx == 0.0f && ny == 0.0f && nz == 0.0f);
+}
+
+struct Tri {
+  int32_t index;
+  double n[3];   // unit normal (the float normal, renormalised in double)
+  double c[3];   // centroid, split key
+  double extra;  // how far the corners leave the plane N.(x - p1) = 0
+};
+
+struct Builder {
+  const float *v; // 9 floats per triangle
+  std::vector<Tri> tri;
+  std::vector<int32_t> order; // positions in `tri`
+  TriBvhHost *out;
+
+  struct Bound {
+    float4 s, n;
+    float spread;
+  };
+
+  Bound bound(int b, int e, int &axis) const {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double sum[3] = {0, 0, 0};
+    const Tri &first = tri[order[b]];
+    for (int k = b; k < e; k++) {
+      const Tri &T = tri[order[k]];
+      const float *p = v + 9 * (size_t)T.index;
+      for (int c = 0; c < 3; c++)
+        for (int d = 0; d < 3; d++) {
+          lo[d] = std::min(lo[d], (double)p[3 * c + d]);
+          hi[d] = std::max(hi[d], (double)p[3 * c + d]);
+        }
+      for (int d = 0; d < 3; d++) {
+        clo[d] = std::min(clo[d], T.c[d]);
+        chi[d] = std::max(chi[d], T.c[d]);
+      }
+      // N and -N mirror the origin to the same point: fold to one side
+      const double sg = T.n[0] * first.n[0] + T.n[1] * first.n[1] + T.n[2] * first.n[2] < 0 ? -1 : 1;
+      for (int d = 0; d < 3; d++)
+        sum[d] += sg * T.n[d];
+    }
+    axis = 0;
+    for (int d = 1; d < 3; d++)
+      if (chi[d] - clo[d] > chi[axis] - clo[axis])
+        axis = d;
+    const float cf[3] = {(float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])),
+                         (float)(0.5 * (lo[2] + hi[2]))};
+    double sl = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+    double mean[3];
+    if (sl > 1e-6 * (e - b))
+      for (int d = 0; d < 3; d++)
+        mean[d] = sum[d] / sl;
+    else
+      for (int d = 0; d < 3; d++)
+        mean[d] = first.n[d];
+    const float nf[3] = {(float)mean[0], (float)mean[1], (float)mean[2]};
+    const double nl = std::sqrt((double)nf[0] * nf[0] + (double)nf[1] * nf[1] + (double)nf[2] * nf[2]);
+    double R = 0, s = 0;
+    for (int k = b; k < e; k++) {
+      const Tri &T = tri[order[k]];
+      const float *p = v + 9 * (size_t)T.index;
+      for (int c = 0; c < 3; c++) {
+        const double dx = p[3 * c] - (double)cf[0], dy = p[3 * c + 1] - (double)cf[1],
+                     dz = p[3 * c + 2] - (double)cf[2];
+        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + 1.01 * T.extra);
+      }
+      double dm = 0, dp = 0;
+      for (int d = 0; d < 3; d++) {
+        const double u = nf[d] / nl;
+        dm += (T.n[d] - u) * (T.n[d] - u);
+        dp += (T.n[d] + u) * (T.n[d] + u);
+      }
+      s = std::max(s, std::sqrt(std::min(dm, dp)));
+    }
+    s += 1e-7;
+    Bound B;
+    B.s = make_float4(cf[0], cf[1], cf[2], round_up(R * (1.0 + 1e-6)));
+    B.n = make_float4(nf[0], nf[1], nf[2],
+                      round_up((2.0 * s * (1.0 + 2.0 * s) + 1.0 / 4096.0) * (1.0 + 1e-6)));
+    B.spread = round_up(s + 1.0 / 262144.0);
+    return B;
+  }
+
+  void split(int b, int e, int &m) {
+    int axis;
+    (void)bound(b, e, axis);
+    m = b + (e - b) / 2;
+    std::nth_element(order.begin() + b, order.begin() + m, order.begin() + e,
+                     [&](int32_t x, int32_t y) {
+                       const double vx = tri[x].c[axis], vy = tri[y].c[axis];
+                       return vx < vy || (vx == vy && x < y);
+                     });
+  }
+
+  int32_t build(int b, int e, Bound &me_bound) {
+    int axis;
+    me_bound = bound(b, e, axis);
+    if (e - b == 1) {
+      const int slot = (int)out->leaf_idx.size();
+      out->leaf_idx.push_back(tri[order[b]].index);
+      return ~(slot << 3);
+    }
+    int m;
+    split(b, e, m);
+    int parts = 0, lo[4], hi[4];
+    const int halves[2][2] = {{b, m}, {m, e}};
+    for (int h = 0; h < 2; h++) {
+      const int hb = halves[h][0], he = halves[h][1];
+      if (he - hb >= 2) {
+        int mm;
+        split(hb, he, mm);
+        lo[parts] = hb;
+        hi[parts++] = mm;
+        lo[parts] = mm;
+        hi[parts++] = he;
+      } else if (he - hb == 1) {
+        lo[parts] = hb;
+        hi[parts++] = he;
+      }
+    }
+    const int me = (int)out->nodes.size();
+    out->nodes.push_back(TriNode{});
+    Bound cb[BVH_WIDTH];
+    int32_t cl[BVH_WIDTH];
+    for (int k = 0; k < BVH_WIDTH; k++) {
+      if (k < parts) {
+        cl[k] = build(lo[k], hi[k], cb[k]);
+      } else {
+        cl[k] = BVH_EMPTY;
+        cb[k].s = cb[k].n = make_float4(0.f, 0.f, 0.f, 0.f);
+        cb[k].spread = 0.f;
+      }
+    }
+    TriNode &N = out->nodes[me];
+    for (int k = 0; k < BVH_WIDTH; k++) {
+      N.s[k] = cb[k].s;
+      N.n[k] = cb[k].n;
+      N.spread[k] = cb[k].spread;
+      N.link[k] = cl[k];
+    }
+    return me;
+  }
+};
+
+} // namespace
+
+void tri_bvh_build(const float *tris, int n, TriBvhHost &out) {
+  out.nodes.clear();
+  out.leaf_idx.clear();
+  out.loose.clear();
+  out.valid = false;
+  if (n <= 0)
+    return;
+  Builder B;
+  B.v = tris;
+  B.out = &out;
+  B.tri.reserve(n);
+  for (int i = 0; i < n; i++) {
+    const float *p = tris + 9 * (size_t)i;
+    float Nf[3];
+    if (!float_normal(p, p + 3, p + 6, Nf))
+      continue; // can never be reported as hit
+    bool big = false;
+    for (int k = 0; k < 9; k++)
+      big |= !(std::fabs(p[k]) <= 1e18f);
+    // shape checks, in double on the float data
+    Tri T;
+    T.index = i;
+    const double nl = std::sqrt((double)Nf[0] * Nf[0] + (double)Nf[1] * Nf[1] + (double)Nf[2] * Nf[2]);
+    for (int d = 0; d < 3; d++) {
+      T.n[d] = Nf[d] / nl;
+      T.c[d] = ((double)p[d] + p[3 + d] + p[6 + d]) / 3.0;
+    }
+    // the float edge vectors the inside tests use (maths.cpp:92,101,110)
+    const float ef[3][3] = {{p[3] - p[0], p[4] - p[1], p[5] - p[2]},
+                            {p[6] - p[3], p[7] - p[4], p[8] - p[5]},
+                            {p[0] - p[6], p[1] - p[7], p[2] - p[8]}};
+    double el[3], diam = 0;
+    bool ok = !big;
+    for (int k = 0; k < 3 && ok; k++) {
+      el[k] = std::sqrt((double)ef[k][0] * ef[k][0] + (double)ef[k][1] * ef[k][1] +
+                        (double)ef[k][2] * ef[k][2]);
+      diam = std::max(diam, el[k]);
+      if (!(el[k] > 0))
+        ok = false;
+    }
+    if (ok) {
+      // N must be (nearly) perpendicular to every edge, or the prism the inside
+      // tests describe is not the triangle's own
+      for (int k = 0; k < 3; k++) {
+        const double ne = std::fabs(T.n[0] * ef[k][0] + T.n[1] * ef[k][1] + T.n[2] * ef[k][2]);
+        if (!(ne <= 0.4 * el[k]))
+          ok = false;
+      }
+      const double a1 = std::fabs(T.n[0] * ((double)p[3] - p[0]) + T.n[1] * ((double)p[4] - p[1]) +
+                                  T.n[2] * ((double)p[5] - p[2]));
+      const double a2 = std::fabs(T.n[0] * ((double)p[6] - p[0]) + T.n[1] * ((double)p[7] - p[1]) +
+                                  T.n[2] * ((double)p[8] - p[2]));
+      T.extra = std::max(a1, a2);
+      if (!(T.extra <= 0.01 * diam))
+        ok = false;
+      // sharpest corner: a rounding allowance d on each edge reaches d / sin(angle/2)
+      // beyond the corner; the device's allowance assumes a factor <= 64
+      for (int k = 0; k < 3 && ok; k++) {
+        const int j = (k + 2) % 3; // edges k and j meet at corner k: e_k and -e_j
+        const double cosang = -((double)ef[k][0] * ef[j][0] + (double)ef[k][1] * ef[j][1] +
+                                (double)ef[k][2] * ef[j][2]) /
+                              (el[k] * el[j]);
+        const double half_sin = std::sqrt(std::max(0.0, (1.0 - cosang) * 0.5));
+        if (!(half_sin * 64.0 >= 1.0))
+          ok = false;
+      }
+    }
+    if (!ok) {
+      out.loose.push_back(i);
+      continue;
+    }
+    B.tri.push_back(T);
+  }
+  const int m = (int)B.tri.size();
+  out.valid = true;
+  if (m == 0)
+    return; // everything is loose or unhittable: no nodes
+  B.order.resize(m);
+  std::iota(B.order.begin(), B.order.end(), 0);
+  out.leaf_idx.reserve(m);
+  Builder::Bound root;
+  if (m == 1) {
+    out.nodes.push_back(TriNode{});
+    const int32_t l = B.build(0, 1, root);
+    TriNode &N = out.nodes[0];
+    for (int k = 0; k < BVH_WIDTH; k++) {
+      N.s[k] = root.s;
+      N.n[k] = root.n;
+      N.spread[k] = root.spread;
+      N.link[k] = k == 0 ? l : BVH_EMPTY;
+    }
+  } else {
+    (void)B.build(0, m, root); // node 0 is the root
+  }
+}
+
+} // namespace rt

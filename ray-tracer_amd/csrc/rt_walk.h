@@ -12,6 +12,10 @@
 //   k_shade         hit list           -> per light: shadow-ray items; next level's rays
 //   k_walk<true>    shadow-ray items   -> integer light added to the pixel if unoccluded
 //
+// k_walk exists per class of primitive.  A scene with a triangle hierarchy runs
+// the triangle walk before the sphere walk in both places; with only a handful
+// of triangles k_shade loops over them instead.
+//
 // The arithmetic per ray and per primitive is the same trace described in
 // rt_device.h; only the scheduling differs.  Results cannot depend on it: the
 // nearest-hit rule is order independent (smallest |P|, lowest index on ties) and
@@ -86,17 +90,20 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
   return false;
 }
 
-// k_walk — spheres only.  Each lane walks the hierarchy for one queue item at a
-// time and fetches the next item when it is done.
-//   ANY_HIT = false: item = bounce ray; result (P, |P|, sphere index or -1) is
-//                    written to hits[slot of the ray]
-//   ANY_HIT = true : item = shadow ray (tagA = pixel, tagB = packed light);
-//                    the light is added to the pixel if no sphere is hit
-// Leaves are single spheres.  Running the exact test the moment a leaf is touched
-// would make every iteration of the wave pay for it with one or two lanes
+// k_walk — each lane walks one hierarchy (TRI: the triangles', else the
+// spheres') for one queue item at a time and fetches the next item when it is
+// done.
+//   ANY_HIT = false: item = bounce ray; the nearest hit of this class (P, |P|,
+//                    index or -1) is written to hits[slot of the ray]
+//   ANY_HIT = true : item = shadow ray (tagA = pixel, tagB = packed light).
+//                    Spheres: the light is added to the pixel if no sphere is hit.
+//                    Triangles: an occluded item is cancelled in place (direction
+//                    0, light 0) so that the sphere walk which follows drops it.
+// Leaves are single primitives.  Running the exact test the moment a leaf is
+// touched would make every iteration of the wave pay for it with one or two lanes
 // active, so a lane parks up to four touched leaves and the whole wave works
 // them off together whenever it stops to refill.
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool TRI>
 __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   const int lane = threadIdx.x & 63;
   // this block serves segment (block % n_seg) of the queue together with the
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   enum { EMPTY = 0, BUSY = 1, DRAIN = 2 }; // DRAIN: walk over, parked leaves left
   int state = EMPTY;
   uint32_t ray = 0, tagA = 0, tagB = 0;
-  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, a = 0, a4 = 0, da = 0;
+  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, a = 0, a4 = 0, da = 0, ol = 0;
   float len_s = RT_INF, bound = RT_INF;
   int idx_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
@@ -121,6 +128,14 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   uint32_t n_rays = 0;
   bool drained = false;
 
+  // exact test of leaf `slot` for this lane's ray, folded into its nearest hit
+  auto leaf = [&](int slot) -> bool {
+    if (TRI)
+      return tri_fold(sc.tleaf[slot], sc.tleaf_idx[slot], ox, oy, oz, dx, dy, dz, len_s, idx_s,
+                      sPx, sPy, sPz);
+    return leaf_test(sc, slot, a, a4, ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy, sPz);
+  };
+
   while (true) {
     const int n_free = __builtin_popcountll(__ballot(state != BUSY));
     if (n_free == 64 || (!drained && n_free >= WALK_FETCH_AT)) {
@@ -129,8 +144,7 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
         if (n_park > 0) {
           const int slot = n_park == 1 ? p0 : n_park == 2 ? p1 : n_park == 3 ? p2 : p3;
           n_park--;
-          if (!(ANY_HIT && idx_s >= 0) &&
-              leaf_test(sc, slot, a, a4, ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy, sPz)) {
+          if (!(ANY_HIT && idx_s >= 0) && leaf(slot)) {
             if (ANY_HIT)
               state = DRAIN; // occluded: nothing more to find
             else
@@ -141,8 +155,12 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
       // ---- hand in finished items ----
       if (state == DRAIN) {
         if (ANY_HIT) {
-          if (idx_s < 0) // unoccluded: renderer.cpp:119-127, as an integer sum
+          if (TRI) {
+            if (idx_s >= 0) // blocked by a triangle: cancel the item
+              w.in.items[2 * (seg_base + ray) + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else if (idx_s < 0) { // unoccluded: renderer.cpp:119-127, as an integer sum
             add_light(w.extra, tagA, tagB);
+          }
         } else {
           w.hits.rec[seg_base + ray] = make_float4(sPx, sPy, sPz, len_s);
           w.hits.idx[seg_base + ray] = idx_s;
@@ -178,36 +196,65 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
               n_rays++;
               len_s = RT_INF;
               idx_s = -1;
-              a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
-              a4 = 4.0f * a;
-              da = __builtin_amdgcn_sqrtf(a) * 1.001f; // >= |d|
               bound = RT_INF;
               sp = 0;
               node = 0;
               n_park = 0;
               state = BUSY;
-              const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
-              if (!(a > 0.f) || sc.s_size == 0) {
-                state = DRAIN; // no sphere can be hit (rt_device.h, beam screen notes)
-              } else if (!sane || sc.bvh == nullptr) {
-                // out-of-range direction length: this lane tests every sphere
-                for (int i = 0; i < sc.s_size; i++) {
-                  const float4 g = sc.sph_geo[i];
-                  float Px, Py, Pz;
-                  if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
-                    const float len = length3(Px, Py, Pz);
-                    if (len_s > len) {
-                      len_s = len;
-                      idx_s = i;
-                      sPx = Px;
-                      sPy = Py;
-                      sPz = Pz;
-                      if (ANY_HIT)
-                        break;
+              if (TRI) {
+                const TriWalkRay tr = tri_walk_ray(ox, oy, oz, dx, dy, dz);
+                a = tr.a;
+                da = tr.da;
+                ol = tr.ol;
+                if (!tr.possible) {
+                  state = DRAIN;
+                } else {
+                  bool found = false;
+                  for (int k = 0; k < sc.n_tloose && !(ANY_HIT && found); k++) {
+                    const int i = sc.tloose[k];
+                    found |= tri_fold(sc.tri[i], i, ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy,
+                                      sPz);
+                  }
+                  if (!tr.usable) // out-of-range numbers: this lane tests every triangle
+                    for (int slot = 0; slot < sc.n_tleaf && !(ANY_HIT && found); slot++)
+                      found |= leaf(slot);
+                  if (!tr.usable || sc.n_tleaf == 0 || (ANY_HIT && found))
+                    state = DRAIN;
+                  else if (!ANY_HIT)
+                    bound = len_s;
+                }
+              } else {
+                a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
+                a4 = 4.0f * a;
+                da = __builtin_amdgcn_sqrtf(a) * 1.001f; // >= |d|
+                // a sphere only matters if it is strictly nearer than the ray's
+                // nearest triangle (renderer.cpp:181)
+                if (!ANY_HIT && w.prior.idx != nullptr && w.prior.idx[seg_base + r] >= 0)
+                  bound = w.prior.rec[seg_base + r].w;
+                const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
+                if (!(a > 0.f) || sc.s_size == 0) {
+                  state = DRAIN; // no sphere can be hit (rt_device.h, beam screen notes)
+                } else if (!sane || sc.bvh == nullptr) {
+                  // out-of-range direction length: this lane tests every sphere
+                  for (int i = 0; i < sc.s_size; i++) {
+                    const float4 g = sc.sph_geo[i];
+                    float Px, Py, Pz;
+                    if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py,
+                                     Pz)) {
+                      const float len = length3(Px, Py, Pz);
+                      if (len_s > len) {
+                        len_s = len;
+                        idx_s = i;
+                        sPx = Px;
+                        sPy = Py;
+                        sPz = Pz;
+                        if (ANY_HIT)
+                          break;
+                      }
                     }
                   }
+                  state = DRAIN;
                 }
-                state = DRAIN;
               }
             }
           }
@@ -220,15 +267,35 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
 
     if (state == BUSY) {
       // ---- one node visit: the bounds of its (up to four) children ----
-      const BvhNode N = sc.bvh[node];
       int next = -1;
       float next_near = RT_INF;
+      int32_t links[BVH_WIDTH];
+      float nears[BVH_WIDTH];
+      bool touch[BVH_WIDTH];
+      if (TRI) {
+        const TriNode N = sc.tbvh[node];
+#pragma unroll
+        for (int c = 0; c < BVH_WIDTH; c++) {
+          links[c] = N.link[c];
+          nears[c] = RT_INF;
+          touch[c] = links[c] != BVH_EMPTY &&
+                     tri_touches(N.s[c], N.n[c], N.spread[c], ox, oy, oz, dx, dy, dz, a, da, ol,
+                                 bound, nears[c]);
+        }
+      } else {
+        const BvhNode N = sc.bvh[node];
+#pragma unroll
+        for (int c = 0; c < BVH_WIDTH; c++) {
+          links[c] = N.link[c];
+          nears[c] = N.near[c];
+          touch[c] = links[c] != BVH_EMPTY &&
+                     bvh_touches(N.s[c], N.near[c], ox, oy, oz, dx, dy, dz, a, da, bound);
+        }
+      }
 #pragma unroll
       for (int c = 0; c < BVH_WIDTH; c++) {
-        const int32_t link = N.link[c];
-        const bool t = link != BVH_EMPTY &&
-                       bvh_touches(N.s[c], N.near[c], ox, oy, oz, dx, dy, dz, a, da, bound);
-        if (t && link < 0) {
+        const int32_t link = links[c];
+        if (touch[c] && link < 0) {
           // a touched leaf is parked (or, with four already parked, tested now)
           const int slot = (~link) >> 3;
           if (n_park < 4) {
@@ -241,19 +308,18 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
             else
               p3 = slot;
             n_park++;
-          } else if (leaf_test(sc, slot, a, a4, ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy,
-                               sPz)) {
+          } else if (leaf(slot)) {
             if (!ANY_HIT)
               bound = fminf(bound, len_s);
           }
-        } else if (t) {
+        } else if (touch[c]) {
           // visit the child nearest to the world origin next (it tightens
           // `bound`), stack the others
           int push = link;
-          if (N.near[c] < next_near) {
+          if (nears[c] < next_near) {
             push = next;
             next = link;
-            next_near = N.near[c];
+            next_near = nears[c];
           }
           if (push >= 0 && sp < BVH_STACK)
             stack[sp++] = push;
@@ -310,7 +376,18 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, ShadeArgs s) {
       const float len_s = idx_s >= 0 ? sh.w : RT_INF;
       float len_t = RT_INF, tPx = 0, tPy = 0, tPz = 0;
       int idx_t = -1;
-      lane_triangles(sc, false, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
+      if (sc.tbvh != nullptr) { // found by k_walk<false, true>
+        idx_t = s.tri_hits.idx[seg_base + i];
+        if (idx_t >= 0) {
+          const float4 th = s.tri_hits.rec[seg_base + i];
+          tPx = th.x;
+          tPy = th.y;
+          tPz = th.z;
+          len_t = th.w;
+        }
+      } else {
+        lane_triangles(sc, false, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
+      }
       if (idx_t >= 0 || idx_s >= 0) { // renderer.cpp:179-192
         if (len_t <= len_s) {
           h.kind = 1;
@@ -348,13 +425,16 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, ShadeArgs s) {
         bool blocked = false;
         if (lit) {
           angle = phong_light(sf, h, dx, dy, dz, sc.lights[l], fColor, lx, ly, lz);
-          // renderer.cpp:119: the shadow ray starts exactly at P; its triangles here
-          float len_t = RT_INF, tx, ty, tz;
-          int idx_t = -1;
-          lane_triangles(sc, true, h.Px, h.Py, h.Pz, lx, ly, lz, len_t, idx_t, tx, ty, tz);
-          blocked = idx_t >= 0;
-          if (blocked)
-            n_rays++; // traced to the end here; the others are counted by the walk
+          // renderer.cpp:119: the shadow ray starts exactly at P; its triangles
+          // here, unless a hierarchy walk over the triangles follows
+          if (sc.tbvh == nullptr) {
+            float len_t = RT_INF, tx, ty, tz;
+            int idx_t = -1;
+            lane_triangles(sc, true, h.Px, h.Py, h.Pz, lx, ly, lz, len_t, idx_t, tx, ty, tz);
+            blocked = idx_t >= 0;
+            if (blocked)
+              n_rays++; // traced to the end here; the others are counted by the walk
+          }
         }
         const uint32_t c0 = (uint32_t)((fColor[0] * angle) * wl),
                        c1 = (uint32_t)((fColor[1] * angle) * wl),

@@ -250,6 +250,12 @@ class DeviceScene:
             _check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(f),
                                           dev_ray_count))
 
+    def queue_overflowed(self) -> bool:
+        """rt_scene_queue_overflowed: did the last frame drop bounce rays?"""
+        flag = C.c_int(0)
+        _check(lib().rt_scene_queue_overflowed(self.handle, C.byref(flag)))
+        return bool(flag.value)
+
     def check_intersection(self, orig: np.ndarray, dir: np.ndarray):
         orig = np.ascontiguousarray(orig, np.float32).reshape(-1, 3)
         dir = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
@@ -313,17 +319,29 @@ def material_grid_scene(row: int, col: int, seed: int = 0x5EED) -> Scene:
     return sc
 
 
-def mesh_scene(nx: int, ny: int, grid: int = 10, seed: int = 0x5EED, materials: bool = True) -> Scene:
-    """The triangle-heavy configuration at any size: a displaced height field
-    over x in [-80,80], y in [-45,45], z in [-90,-60] cut into nx*ny quads
-    (2*nx*ny triangles; 1000 x 500 gives the 1 M-triangle scene), plus a
-    grid x grid block of the reference's unit spheres and its light.  Fixed seed."""
+def mesh_scene(nx: int, ny: int, grid: int = 10, seed: int = 0x5EED, materials: bool = True,
+               roughness: float = 0.0) -> Scene:
+    """The triangle-heavy configuration at any size: a smooth height field over
+    x in [-80,80], y in [-45,45], z in [-90,-60] (four seeded sine modes, the same
+    surface at every tessellation) cut into nx*ny quads (2*nx*ny triangles;
+    1000 x 500 gives the 1 M-triangle scene), plus a grid x grid block of the
+    reference's unit spheres and its light.  roughness > 0 adds that much uniform
+    noise to every vertex height (a deliberately hostile mesh for the triangle
+    hierarchy: neighbouring normals then disagree).  Fixed seed."""
     rng = np.random.RandomState(seed)
     xs = np.linspace(-80, 80, nx + 1, dtype=np.float32)
     ys = np.linspace(-45, 45, ny + 1, dtype=np.float32)
     X, Y = np.meshgrid(xs, ys, indexing="ij")
-    Z = (-75 + 9 * np.sin(X * 0.11) * np.cos(Y * 0.17) +
-         rng.uniform(-6, 6, X.shape)).astype(np.float32)
+    amp = (10.0, 3.0, 1.0, 0.3)
+    freq = (0.025, 0.06, 0.1, 0.18)
+    ph = rng.uniform(0, 2 * np.pi, (4, 2))
+    Z = np.full(X.shape, -75.0)
+    for k in range(4):
+        Z += amp[k] * np.sin(freq[k] * X + ph[k, 0]) * np.cos(freq[k] * 1.3 * Y + ph[k, 1])
+    noise = rng.uniform(-1.0, 1.0, X.shape)
+    if roughness > 0:
+        Z += roughness * noise
+    Z = Z.astype(np.float32)
     P = np.stack([X, Y, Z], -1)
     a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
     t1 = np.concatenate([a, b, c], -1).reshape(-1, 9)

@@ -133,8 +133,11 @@ def test_invalid_materials_rejected():
 def test_triangle_mesh_configuration_reduced(oracle):
     """The triangle-heavy configuration (height-field mesh + spheres, materials
     on triangles too) at a size the oracle finishes: 4000 triangles, 256x144,
-    depth 1 and depth 4.  Triangles are looped by every ray."""
-    sc = rtamd.mesh_scene(50, 40)
-    assert sc.t_size == 4000
-    compare(sc, 256, 144, 1, oracle)
-    compare(sc, 256, 144, 4, oracle)
+    depth 1 and depth 4.  The rays walk the triangle hierarchy; the second mesh
+    has noisy vertex heights, so neighbouring normals disagree and the
+    hierarchy's bounds are at their loosest."""
+    for rough in (0.0, 6.0):
+        sc = rtamd.mesh_scene(50, 40, roughness=rough)
+        assert sc.t_size == 4000
+        compare(sc, 256, 144, 1, oracle)
+        compare(sc, 256, 144, 4, oracle)
