@@ -28,18 +28,25 @@ FLOP_PER_SPHERE_TEST = 25       # maths.cpp:126-133 up to the discriminant test
 FLOP_PER_TRIANGLE_TEST = 107    # maths.cpp:68-116 full path
 
 WORKLOADS = {
-    # name: (grid rows, grid cols, width, height, depth, materials)
-    "10k-spheres-4k-depth8": (100, 100, 3840, 2160, 8, True),
-    "10k-spheres-4k-depth1": (100, 100, 3840, 2160, 1, False),
-    "1k-spheres-1080p-depth4": (32, 32, 1920, 1080, 4, True),
-    "1k-spheres-1080p-depth1": (32, 32, 1920, 1080, 1, False),
-    "shipped-1440p-depth1": (10, 10, 2560, 1440, 1, False),
+    # name: (grid rows, grid cols, width, height, depth, materials, mesh quads or None)
+    "10k-spheres-4k-depth8": (100, 100, 3840, 2160, 8, True, None),
+    "10k-spheres-4k-depth1": (100, 100, 3840, 2160, 1, False, None),
+    "1k-spheres-1080p-depth4": (32, 32, 1920, 1080, 4, True, None),
+    "1k-spheres-1080p-depth1": (32, 32, 1920, 1080, 1, False, None),
+    "shipped-1440p-depth1": (10, 10, 2560, 1440, 1, False, None),
+    # the triangle-heavy configuration: 1 M-triangle height field + the 10k spheres
+    "1m-triangles-8k-depth8": (100, 100, 7680, 4320, 8, True, (1000, 500)),
+    "1m-triangles-4k-depth8": (100, 100, 3840, 2160, 8, True, (1000, 500)),
 }
+PLAIN_LOOP_MAX_PRIMS = 20000   # beyond this the every-primitive loop takes minutes per frame
 
 
 def build_scene(name):
-    row, col, w, h, depth, mats = WORKLOADS[name]
-    sc = rtamd.material_grid_scene(row, col) if mats else rtamd.grid_scene(row, col)
+    row, col, w, h, depth, mats, mesh = WORKLOADS[name]
+    if mesh:
+        sc = rtamd.mesh_scene(mesh[0], mesh[1], grid=row, materials=mats)
+    else:
+        sc = rtamd.material_grid_scene(row, col) if mats else rtamd.grid_scene(row, col)
     return sc, w, h, depth
 
 
@@ -50,6 +57,22 @@ def cpu_baseline(sc, w, h, depth, budget_s=20.0):
     from oracle_py import Oracle
     o = Oracle()
     threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    if sc.t_size > PLAIN_LOOP_MAX_PRIMS:
+        # a single row of this frame takes the CPU minutes: sample pixels instead
+        rng = np.random.RandomState(2024)
+        def sample(n):
+            px = np.stack([rng.randint(0, h, n), rng.randint(0, w, n)], 1)
+            t = time.perf_counter()
+            _, _, rays = o.render_pixels(sc, w, h, depth, px)
+            return rays, time.perf_counter() - t
+        r0, dt0 = sample(4 * threads)
+        n = int(max(4 * threads, min(200000, 4 * threads * budget_s / max(dt0, 1e-3))))
+        rays, dt = sample(n)
+        return {
+            "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{n} random pixels ({rays} rays, {dt:.1f} s) of the same {w}x{h} frame; "
+                      f"oracle/rt_oracle.c, gcc -O2 -fopenmp -ffp-contract=off",
+        }
     # calibrate on a sparse sample, then size the real one
     step0 = max(1, h // 32)
     t = time.perf_counter()
@@ -214,7 +237,9 @@ def main():
                                  "frac can exceed 1 (plain_loop = screen off)"},
         }
         out["config"]["screen"] = args.screen
-        if world == 1 and args.screen != "off":
+        if world == 1 and args.screen != "off" and sc.t_size + sc.s_size > PLAIN_LOOP_MAX_PRIMS:
+            out["roofline"]["plain_loop"] = None   # minutes per frame at this size: not run
+        elif world == 1 and args.screen != "off":
             # the same frame with the screen off: the brute-force formulation the
             # FP32 roofline is defined on (every ray against every primitive)
             rtamd.set_screen(False)

@@ -30,6 +30,10 @@ class Oracle:
         L.oracle_render.argtypes = [C.POINTER(rtamd.SceneDesc), C.POINTER(rtamd.Camera),
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int]
+        L.oracle_render_pixels.restype = C.c_uint64
+        L.oracle_render_pixels.argtypes = [C.POINTER(rtamd.SceneDesc), C.POINTER(rtamd.Camera),
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int64, C.c_void_p]
         L.oracle_check_intersection.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p]
@@ -61,6 +65,18 @@ class Oracle:
                                  ids.ctypes.data if want_ids else None, w, h, max_depth,
                                  b, e, s)
         return fb, ids, int(n)
+
+    def render_pixels(self, scene: rtamd.Scene, w, h, max_depth, pixels, cam=None):
+        """pixels: (n, 2) rows and columns of a w x h frame.  Returns
+        (rgba[n,4], ids[n], n_rays) for just those pixels."""
+        cam = cam or rtamd.default_camera()
+        ij = np.ascontiguousarray(pixels, np.int32).reshape(-1, 2)
+        out = np.zeros((len(ij), 4), np.uint8)
+        ids = np.full(len(ij), -2, np.int32)
+        d = scene.desc()
+        n = self.L.oracle_render_pixels(C.byref(d), C.byref(cam), out.ctypes.data, ids.ctypes.data,
+                                        w, h, max_depth, len(ij), ij.ctypes.data)
+        return out, ids, int(n)
 
     def check_intersection(self, scene: rtamd.Scene, orig, dir):
         orig = np.ascontiguousarray(orig, np.float32).reshape(-1, 3)

@@ -448,3 +448,18 @@ uint64_t oracle_render(const scene_desc *sc, const camera *cam, uint8_t *fb,
   }
   return total;
 }
+
+/* The same per-pixel work for a list of n pixels (ij = row, column pairs) of a
+ * w x h frame: out_rgba gets 4 bytes and out_ids (may be NULL) one id per listed
+ * pixel.  Lets a sample of a frame be checked when the whole frame would take
+ * hours on a CPU.  Returns the rays traced. */
+uint64_t oracle_render_pixels(const scene_desc *sc, const camera *cam, uint8_t *out_rgba,
+                              int32_t *out_ids, int w, int h, int max_depth, int64_t n,
+                              const int32_t *ij) {
+  uint64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+  for (int64_t k = 0; k < n; k++)
+    total += shade_pixel(sc, cam, w, h, ij[2 * k], ij[2 * k + 1], max_depth, out_rgba + 4 * k,
+                         out_ids ? out_ids + k : NULL);
+  return total;
+}

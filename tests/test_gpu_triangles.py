@@ -170,3 +170,32 @@ def test_million_triangle_frame_properties():
         rows = np.arange(h) // 8 % 2
         assert np.array_equal(s0[rows == 0], fa[rows == 0])
         assert np.array_equal(s1[rows == 1], fa[rows == 1])
+
+
+def test_million_triangles_8k_depth8_pixel_sample(oracle):
+    """The triangle-heavy configuration at its full size (1 M triangles + 10 000
+    spheres, 7680x4320, depth 8) on one GPU; the oracle renders 1 024 random
+    pixels and four whole 8x8 tiles of it (about 9 000 rays against every
+    primitive) and must agree on ids and bytes."""
+    import torch
+    sc = rtamd.mesh_scene(1000, 500, grid=100)
+    w, h = 7680, 4320
+    dev = torch.device("cuda", 0)
+    fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    ids = torch.zeros(h, w, dtype=torch.int32, device=dev)
+    with rtamd.DeviceScene(sc) as ds:
+        ds.render_device(fb.data_ptr(), ids.data_ptr(), w, h, max_depth=8)
+        torch.cuda.synchronize()
+        assert not ds.queue_overflowed()
+    rng = np.random.RandomState(99)
+    px = [np.stack([rng.randint(0, h, 1024), rng.randint(0, w, 1024)], 1)]
+    for ti, tj in ((0, 0), (270, 480), (100, 900), (539, 959)):
+        ii, jj = np.meshgrid(np.arange(8) + 8 * ti, np.arange(8) + 8 * tj, indexing="ij")
+        px.append(np.stack([ii.ravel(), jj.ravel()], 1))
+    px = np.concatenate(px)
+    want, want_ids, _ = oracle.render_pixels(sc, w, h, 8, px)
+    got = fb.cpu().numpy()[px[:, 0], px[:, 1]]
+    got_ids = ids.cpu().numpy()[px[:, 0], px[:, 1]]
+    assert np.array_equal(got_ids, want_ids)
+    assert np.array_equal(got, want)
+    assert ((want_ids >= 0) & (want_ids < sc.t_size)).sum() > 50
