@@ -158,13 +158,15 @@ void rt_set_screen(int mode);
 int rt_get_screen(void);
 
 /* As rt_render_device, with a slow self-checking build of the kernel that
- * re-tests every sphere the screen dropped.  dev_stats (device, 8 x uint64,
+ * re-tests every sphere the screen dropped.  dev_stats (device, 16 x uint64,
  * zeroed by the caller) receives
  *   [0] wave-level drops for which some ray's discriminant test
  *       (maths.cpp:132-133) passes - must be 0
  *   [1] spheres the screen kept
  *   [2..4] bounce rays walked through the sphere hierarchy, node bounds tested,
- *          leaf spheres tested;  [5..7] the same for the bounce hits' shadow rays */
+ *          leaf spheres tested;  [5..7] the same for the bounce hits' shadow rays
+ *   [8..13] the same six numbers for walks through the triangle hierarchy
+ *   [14..15] unused                                                            */
 int rt_render_device_selfcheck(rt_scene *scene, const camera *cam,
                                const rt_frame *frame, uint64_t *dev_ray_count,
                                uint64_t *dev_stats);

@@ -71,8 +71,8 @@ struct rt_scene {
   DevBuf<int32_t> leaf_idx;
   bool has_bvh = false;
   DevBuf<rt::TriNode> tbvh;
-  DevBuf<rt::TriRec> tleaf;
-  DevBuf<int32_t> tleaf_idx, tloose;
+  DevBuf<rt::TriLeaf> tleaf;
+  DevBuf<int32_t> tloose;
   bool has_tbvh = false;
   bool has_mat_tri = false, has_mat_sph = false;
   bool eye_valid = false;
@@ -111,9 +111,8 @@ struct rt_scene {
     const bool use_tbvh = has_tbvh && g_screen != 0;
     d.tbvh = use_tbvh ? tbvh.p : nullptr;
     d.tleaf = use_tbvh ? tleaf.p : nullptr;
-    d.tleaf_idx = use_tbvh ? tleaf_idx.p : nullptr;
     d.tloose = use_tbvh ? tloose.p : nullptr;
-    d.n_tleaf = use_tbvh ? (int)tleaf_idx.n : 0;
+    d.n_tleaf = use_tbvh ? (int)tleaf.n : 0;
     d.n_tloose = use_tbvh ? (int)tloose.n : 0;
     return d;
   }
@@ -247,13 +246,15 @@ int scene_build(rt_scene *S, const scene_desc *s) {
     rt::tri_bvh_build(s->tris, s->t_size, H);
     S->has_tbvh = H.valid && !H.nodes.empty();
     if (S->has_tbvh) {
+      DevBuf<int32_t> order; // leaf slot -> triangle; only the gather needs it
       if ((rc = upload(S->tbvh, H.nodes.data(), H.nodes.size())) ||
-          (rc = upload(S->tleaf_idx, H.leaf_idx.data(), H.leaf_idx.size())) ||
+          (rc = upload(order, H.leaf_idx.data(), H.leaf_idx.size())) ||
           (rc = upload(S->tloose, H.loose.data(), H.loose.size())))
         return rc;
       HIP_TRY(S->tleaf.alloc(H.leaf_idx.size()));
-      HIP_TRY(rt::launch_gather_tri_leaves(S->tri.p, S->tleaf_idx.p, S->tleaf.p,
+      HIP_TRY(rt::launch_gather_tri_leaves(S->tri.p, order.p, S->tleaf.p,
                                            (int)H.leaf_idx.size(), nullptr));
+      HIP_TRY(hipStreamSynchronize(nullptr)); // `order` dies here
     }
   }
   HIP_TRY(hipStreamSynchronize(nullptr)); // staging buffers die here
@@ -483,6 +484,7 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
       tl.idx = tri_walks ? S->tri_hit_idx.p : nullptr;
       rt::WalkArgs wa;
       memset(&wa, 0, sizeof wa);
+      wa.fetch_at = rt::WALK_FETCH_AT;
       wa.in = bd.in;
       wa.extra = S->extra.p;
       // each ray is counted once, by the first walk it goes through
@@ -518,6 +520,7 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
         if (S->l_size > 0) {
           rt::WalkArgs ws;
           memset(&ws, 0, sizeof ws);
+          ws.fetch_at = rt::WALK_FETCH_AT;
           ws.in = sa.shadow;
           ws.extra = S->extra.p;
           if (tri_walks) {

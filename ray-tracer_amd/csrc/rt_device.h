@@ -53,8 +53,7 @@ struct SceneDev {
   const int32_t *leaf_idx;   // original sphere index of each leaf slot
   // hierarchy over the triangles (rt_tribvh.h); tbvh == nullptr: none, loop
   const TriNode *tbvh;
-  const TriRec *tleaf;       // triangle records gathered into leaf order
-  const int32_t *tleaf_idx;  // original triangle index of each leaf slot
+  const TriLeaf *tleaf;      // the triangles in leaf order, with their indices
   const int32_t *tloose;     // triangles outside the hierarchy, tested by every ray
   int n_tleaf, n_tloose;
 };
@@ -340,6 +339,7 @@ struct ScreenStats { // filled only by the verification build of the kernels
   unsigned long long *dropped_but_candidate;
   unsigned long long *kept;
   unsigned long long *walk; // [0] rays walked, [1] node bounds tested, [2] leaf spheres tested
+  unsigned long long *twalk = nullptr; // the same three for the triangle hierarchy
 };
 
 #define RT_BEAM_NONE 0
@@ -404,15 +404,28 @@ __device__ __forceinline__ bool bvh_touches(float4 s, float near, float ox, floa
 // So Q~ lies within R + lam + 2^-13 (|o| + R) + e1 of the centre, and o'_i within
 // |o| (K - 2^-12) of the mean mirrored origin q = o - 2 (n.o) n (K = n.w).  With
 // |o| + |p1| <= 2|o| + |M| + R =: S,
-//   Rtot = R (1 + 2^-12) + |o| K + 2^-16 |M| + 2^-21 S (1 + |d| / ndmin)
+//   Rtot = R (1 + 2^-12) + |o| K + 2e-5 |M| + 2^-21 S (1 + |d| / ndmin)
 // bounds the distance from the centre to the line {q + t d} for every possible
 // hit, t~ |d|^2 <= (C - q).d + Rtot |d| (so a child entirely behind q cannot be
 // hit: maths.cpp:80 rejects t < 0), and |P~| >= |C + (o - q)| - Rtot.  NaN or inf
 // anywhere answers yes.  `ol` >= |o|, `da` >= |d|.
-__device__ __forceinline__ bool tri_touches(float4 s, float4 n, float spread, float ox,
-                                            float oy, float oz, float dx, float dy, float dz,
-                                            float a, float da, float ol, float bound,
-                                            float &near_out) {
+__device__ __forceinline__ bool tri_touches(float4 s, uint2 ns, float ox, float oy, float oz,
+                                            float dx, float dy, float dz, float a, float da,
+                                            float ol, float bound, float &near_out) {
+  // unpack: the normal's 16-bit fractions (its length is within 5e-5 of 1, which
+  // the builder has added to the spread), the spread as a half float
+  float4 n;
+  n.x = (float)(int16_t)(ns.x & 0xffffu) * (1.0f / 32767.0f);
+  n.y = (float)(int16_t)(ns.x >> 16) * (1.0f / 32767.0f);
+  n.z = (float)(int16_t)(ns.y & 0xffffu) * (1.0f / 32767.0f);
+  union {
+    unsigned short u;
+    _Float16 h;
+  } cv;
+  cv.u = (unsigned short)(ns.y >> 16);
+  const float sp = (float)cv.h;
+  n.w = fmaf(2.0f * sp, fmaf(2.0f, sp, 1.0f), 0.000244140625f) * 1.000001f; // K
+  const float spread = sp + 3.814697265625e-06f;                            // + 2^-18
   const float no2 = 2.0f * fmaf(n.z, oz, fmaf(n.y, oy, n.x * ox));
   const float qx = fmaf(-no2, n.x, ox), qy = fmaf(-no2, n.y, oy), qz = fmaf(-no2, n.z, oz);
   const float Mx = s.x - qx, My = s.y - qy, Mz = s.z - qz;
@@ -420,11 +433,11 @@ __device__ __forceinline__ bool tri_touches(float4 s, float4 n, float spread, fl
   const float md = fmaf(dz, Mz, fmaf(dy, My, dx * Mx));
   const float mlen = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
   const float nbd = fabsf(fmaf(n.z, dz, fmaf(n.y, dy, n.x * dx)));
-  const float ndmin = fmaxf(fmaf(-spread, da, nbd) * 0.999999f, 9.9e-5f);
+  const float ndmin = fmaxf(fmaf(-spread, da, nbd * 0.9999f) * 0.999999f, 9.9e-5f);
   const float S = fmaf(2.0f, ol, mlen + s.w);
   const float lam = (S * 4.76837158203125e-07f) *
                     fmaf(da * 1.00001f, __builtin_amdgcn_rcpf(ndmin), 1.0f); // 2^-21
-  const float Rtot = fmaf(s.w, 1.000245f, fmaf(ol, n.w, fmaf(mlen, 1.6e-5f, lam)));
+  const float Rtot = fmaf(s.w, 1.000245f, fmaf(ol, n.w, fmaf(mlen, 2e-5f, lam)));
   const float lhs = fmaf(-md, md, (a * m2) * 0.99999809265136719f);
   const float rhs = (a * Rtot) * (Rtot * 1.000001f);
   const bool behind = fmaf(da, Rtot * 1.0001f, md) < 0.f;
@@ -457,6 +470,22 @@ __device__ __forceinline__ bool tri_fold(const TriRec &T, int idx, float ox, flo
   return false;
 }
 
+// The same for a leaf of the hierarchy: the edge vectors are the float
+// differences k_prep_scene stores in a TriRec (maths.cpp:92,101,110).
+__device__ __forceinline__ bool tri_fold_leaf(const TriLeaf &L, float ox, float oy, float oz,
+                                              float dx, float dy, float dz, float &len_t,
+                                              int &idx_t, float &tPx, float &tPy, float &tPz) {
+  TriRec T;
+  T.n_d = L.n_d;
+  T.p1_no = make_float4(L.a.x, L.a.y, L.a.z, 0.f);
+  T.p2 = make_float4(L.a.w, L.b.x, L.b.y, 0.f);
+  T.p3 = make_float4(L.b.z, L.b.w, L.c.x, 0.f);
+  T.e0 = make_float4(T.p2.x - T.p1_no.x, T.p2.y - T.p1_no.y, T.p2.z - T.p1_no.z, 0.f);
+  T.e1 = make_float4(T.p3.x - T.p2.x, T.p3.y - T.p2.y, T.p3.z - T.p2.z, 0.f);
+  T.e2 = make_float4(T.p1_no.x - T.p3.x, T.p1_no.y - T.p3.y, T.p1_no.z - T.p3.z, 0.f);
+  return tri_fold(T, __float_as_int(L.c.y), ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
+}
+
 // Per-ray constants of the triangle walk.  `usable` false: the ray's numbers
 // are outside the range the bounds were derived for and every triangle must
 // be tested; `possible` false: no triangle can be reported at all (d = 0 gives
@@ -480,10 +509,11 @@ __device__ __forceinline__ TriWalkRay tri_walk_ray(float ox, float oy, float oz,
 
 // Every triangle for one lane's ray through the hierarchy (same result as the
 // loop of renderer.cpp:156-166).
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool VERIFY = false>
 __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, float oy, float oz,
                                                float dx, float dy, float dz, float &len_t,
-                                               int &idx_t, float &tPx, float &tPy, float &tPz) {
+                                               int &idx_t, float &tPx, float &tPy, float &tPz,
+                                               unsigned long long *counters = nullptr) {
   const TriWalkRay r = tri_walk_ray(ox, oy, oz, dx, dy, dz);
   if (!r.possible)
     return;
@@ -496,8 +526,7 @@ __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, flo
     return;
   if (!r.usable) {
     for (int slot = 0; slot < sc.n_tleaf; slot++)
-      if (tri_fold(sc.tleaf[slot], sc.tleaf_idx[slot], ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx,
-                   tPy, tPz) &&
+      if (tri_fold_leaf(sc.tleaf[slot], ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz) &&
           ANY_HIT)
         return;
     return;
@@ -505,16 +534,18 @@ __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, flo
   int stack[BVH_STACK];
   int sp = 0, node = 0;
   float bound = ANY_HIT ? RT_INF : len_t;
+  unsigned n_bounds = 0, n_leaf = 0;
   while (true) {
     const TriNode N = sc.tbvh[node];
     int next = -1;
     float next_near = RT_INF;
+    n_bounds += BVH_WIDTH;
 #pragma unroll
     for (int c = 0; c < BVH_WIDTH; c++) {
       const int32_t link = N.link[c];
       float near;
-      if (link == BVH_EMPTY || !tri_touches(N.s[c], N.n[c], N.spread[c], ox, oy, oz, dx, dy, dz,
-                                            r.a, r.da, r.ol, bound, near))
+      if (link == BVH_EMPTY ||
+          !tri_touches(N.s[c], N.ns[c], ox, oy, oz, dx, dy, dz, r.a, r.da, r.ol, bound, near))
         continue;
       if (link >= 0) {
         int push = link;
@@ -527,20 +558,28 @@ __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, flo
           stack[sp++] = push;
       } else {
         const int slot = (~link) >> 3;
-        if (tri_fold(sc.tleaf[slot], sc.tleaf_idx[slot], ox, oy, oz, dx, dy, dz, len_t, idx_t,
-                     tPx, tPy, tPz)) {
+        n_leaf++;
+        if (tri_fold_leaf(sc.tleaf[slot], ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz)) {
           if (ANY_HIT)
-            return;
-          bound = fminf(bound, len_t);
+            next = -1, sp = 0; // nothing more to find
+          else
+            bound = fminf(bound, len_t);
         }
       }
     }
+    if (ANY_HIT && idx_t >= 0)
+      break;
     if (next >= 0)
       node = next;
     else if (sp > 0)
       node = stack[--sp];
     else
-      return;
+      break;
+  }
+  if (VERIFY && counters) {
+    atomicAdd(counters + 0, 1ull);
+    atomicAdd(counters + 1, (unsigned long long)n_bounds);
+    atomicAdd(counters + 2, (unsigned long long)n_leaf);
   }
 }
 
@@ -557,7 +596,8 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   // ---- triangles, renderer.cpp:156-166 ----
   if (sc.tbvh != nullptr) {
     if (live)
-      walk_triangles<ANY_HIT>(sc, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
+      walk_triangles<ANY_HIT, VERIFY>(sc, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz,
+                                      st.twalk);
   } else {
     for (int i = 0; i < sc.t_size; i++) {
       const TriRec &T = sc.tri[i];

@@ -69,6 +69,9 @@ struct BounceDev {
 };
 
 // Bounce levels as separate launches (rt_walk.h).
+// Refill threshold: 4..48 measured on the 10k-sphere depth-8 frame, 11.98 ms at 4,
+// 10.72 at 16, 10.53 at 24, 10.66 at 48.
+constexpr int WALK_FETCH_AT = 24;
 struct WalkArgs {
   RayQueue in;        // items to walk: (origin, tagA bits), (direction, tagB bits)
   uint32_t *cursor;   // cursor[s * CTL_WORDS]: next item of segment s to hand out
@@ -77,6 +80,7 @@ struct WalkArgs {
   unsigned long long *extra; // shadow walks: tagA = pixel, tagB = packed integer
                              // light, added to the pixel if unoccluded
   uint64_t *ray_count;
+  int fetch_at;       // refill a wave when this many of its lanes have nothing to do
 };
 
 struct ShadeArgs {
@@ -111,8 +115,9 @@ hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
                          const FrameDev &f, const BounceDev &bd,
                          int owned_tile_rows, int accel,
                          unsigned long long *verify_stats, hipStream_t st);
-// verify_stats (device uint64[8] or null): [0..1] as launch_render, [2..4] rays /
-// node bounds / leaf spheres of nearest-hit walks, [5..7] the same for shadow walks.
+// verify_stats (device uint64[16] or null): [0..1] as launch_render, [2..4] rays /
+// node bounds / leaf spheres of nearest-hit walks, [5..7] the same for shadow walks,
+// [8..13] the same six numbers for the triangle hierarchy.
 hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
                          uint64_t *ray_count, unsigned long long *verify_stats,
                          int blocks, hipStream_t st);
@@ -123,7 +128,7 @@ hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixel
                           hipStream_t st);
 hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
                                 float4 *leaf_geo, int n, hipStream_t st);
-hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriRec *leaf,
+hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriLeaf *leaf,
                                     int n, hipStream_t st);
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);
 

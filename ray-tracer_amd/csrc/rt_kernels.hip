@@ -445,6 +445,8 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
     ScreenStats st2 = st;
     if (st2.walk)
       st2.walk += 3; // shadow-ray walks are counted apart from nearest-hit walks
+    if (st2.twalk)
+      st2.twalk += 3;
     n_rays += shade_hits<false, true, BS, VERIFY>(sc, bd, hit, h, b.x, b.y, b.z, a.w, pixel,
                                                   depth, u0, u1, u2, st2);
   }
@@ -561,6 +563,7 @@ hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
     ss.dropped_but_candidate = verify_stats;
     ss.kept = verify_stats + 1;
     ss.walk = verify_stats + 2;
+    ss.twalk = verify_stats + 8;
     hipLaunchKernelGGL((k_bounce<true, true>), dim3(blocks), dim3(256), 0, st, sc, bd,
                        ray_count, ss);
   } else if (beam) {
@@ -618,14 +621,22 @@ __global__ void k_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
     leaf_geo[i] = sph_geo[leaf_idx[i]];
 }
 
-__global__ void k_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriRec *leaf,
+__global__ void k_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriLeaf *leaf,
                                     int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    leaf[i] = tri[leaf_idx[i]];
+  if (i >= n)
+    return;
+  const int32_t t = leaf_idx[i];
+  const TriRec T = tri[t];
+  TriLeaf L;
+  L.n_d = T.n_d;
+  L.a = make_float4(T.p1_no.x, T.p1_no.y, T.p1_no.z, T.p2.x);
+  L.b = make_float4(T.p2.y, T.p2.z, T.p3.x, T.p3.y);
+  L.c = make_float4(T.p3.z, __int_as_float(t), 0.f, 0.f);
+  leaf[i] = L;
 }
 
-hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriRec *leaf,
+hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriLeaf *leaf,
                                     int n, hipStream_t st) {
   if (n <= 0)
     return hipSuccess;

@@ -55,9 +55,28 @@ struct Builder {
   TriBvhHost *out;
 
   struct Bound {
-    float4 s, n;
-    float spread;
+    float4 s;
+    uint2 ns;
   };
+
+  // smallest half float >= x (x >= 0), as bits
+  static uint32_t half_up(double x) {
+    if (!(x > 0))
+      return 0;
+    if (x > 65504.0)
+      return 0x7c00; // +inf
+    int e;
+    double m = std::frexp(x, &e); // x = m 2^e, m in [0.5, 1)
+    uint32_t bits;
+    if (e < -13) { // subnormal: units of 2^-24
+      bits = (uint32_t)std::ceil(x * 16777216.0);
+    } else {
+      // 1.f x 2^(e-1): 10 fraction bits
+      uint32_t f = (uint32_t)std::ceil((m * 2.0 - 1.0) * 1024.0);
+      bits = ((uint32_t)(e - 1 + 15) << 10) + f; // a carry out of f moves to the exponent
+    }
+    return bits;
+  }
 
   Bound bound(int b, int e, int &axis) const {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -95,8 +114,15 @@ struct Builder {
     else
       for (int d = 0; d < 3; d++)
         mean[d] = first.n[d];
-    const float nf[3] = {(float)mean[0], (float)mean[1], (float)mean[2]};
-    const double nl = std::sqrt((double)nf[0] * nf[0] + (double)nf[1] * nf[1] + (double)nf[2] * nf[2]);
+    // the normal as the device will unpack it: 16-bit fractions, then its unit vector
+    int32_t nq[3];
+    double u[3], ul = 0;
+    for (int d = 0; d < 3; d++) {
+      nq[d] = (int32_t)std::lrint(mean[d] * 32767.0);
+      u[d] = (double)(float)nq[d] * (double)(1.0f / 32767.0f);
+      ul += u[d] * u[d];
+    }
+    ul = std::sqrt(ul);
     double R = 0, s = 0;
     for (int k = b; k < e; k++) {
       const Tri &T = tri[order[k]];
@@ -108,18 +134,19 @@ struct Builder {
       }
       double dm = 0, dp = 0;
       for (int d = 0; d < 3; d++) {
-        const double u = nf[d] / nl;
-        dm += (T.n[d] - u) * (T.n[d] - u);
-        dp += (T.n[d] + u) * (T.n[d] + u);
+        const double w = u[d] / ul;
+        dm += (T.n[d] - w) * (T.n[d] - w);
+        dp += (T.n[d] + w) * (T.n[d] + w);
       }
       s = std::max(s, std::sqrt(std::min(dm, dp)));
     }
-    s += 1e-7;
+    // the unpacked normal is not exactly unit: mirroring with it moves the image
+    // of the origin by 2 (|u|^2 - 1) |o|, the same as 2 | |u| - 1 | more spread
+    s += 2.0 * std::fabs(ul - 1.0) + 1e-6;
     Bound B;
     B.s = make_float4(cf[0], cf[1], cf[2], round_up(R * (1.0 + 1e-6)));
-    B.n = make_float4(nf[0], nf[1], nf[2],
-                      round_up((2.0 * s * (1.0 + 2.0 * s) + 1.0 / 4096.0) * (1.0 + 1e-6)));
-    B.spread = round_up(s + 1.0 / 262144.0);
+    B.ns.x = ((uint32_t)nq[0] & 0xffffu) | (((uint32_t)nq[1] & 0xffffu) << 16);
+    B.ns.y = ((uint32_t)nq[2] & 0xffffu) | (half_up(s) << 16);
     return B;
   }
 
@@ -169,15 +196,14 @@ struct Builder {
         cl[k] = build(lo[k], hi[k], cb[k]);
       } else {
         cl[k] = BVH_EMPTY;
-        cb[k].s = cb[k].n = make_float4(0.f, 0.f, 0.f, 0.f);
-        cb[k].spread = 0.f;
+        cb[k].s = make_float4(0.f, 0.f, 0.f, 0.f);
+        cb[k].ns = make_uint2(0u, 0u);
       }
     }
     TriNode &N = out->nodes[me];
     for (int k = 0; k < BVH_WIDTH; k++) {
       N.s[k] = cb[k].s;
-      N.n[k] = cb[k].n;
-      N.spread[k] = cb[k].spread;
+      N.ns[k] = cb[k].ns;
       N.link[k] = cl[k];
     }
     return me;
@@ -273,8 +299,7 @@ void tri_bvh_build(const float *tris, int n, TriBvhHost &out) {
     TriNode &N = out.nodes[0];
     for (int k = 0; k < BVH_WIDTH; k++) {
       N.s[k] = root.s;
-      N.n[k] = root.n;
-      N.spread[k] = root.spread;
+      N.ns[k] = root.ns;
       N.link[k] = k == 0 ? l : BVH_EMPTY;
     }
   } else {

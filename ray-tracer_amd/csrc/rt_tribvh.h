@@ -29,13 +29,27 @@
 
 namespace rt {
 
-struct TriNode {
+// One node = one 128-byte line.  A million triangles make ~50 MB of nodes, far
+// more than the caches hold, and every lane of a wave reads a different node:
+// the walk is bound by the lines it pulls from HBM, so the mean normal is
+// packed to 3 x 16 bits and the spread to a half float (both rounded so that the
+// bound only grows).
+struct alignas(128) TriNode {
   float4 s[BVH_WIDTH];     // centre.xyz, radius (covers the member triangles and the
                            // builder's per-triangle allowances)
-  float4 n[BVH_WIDTH];     // mean unit normal.xyz, K = 2 s (1 + 2s) + 2^-12
-  float spread[BVH_WIDTH]; // s + 2^-18
+  uint2 ns[BVH_WIDTH];     // x: mean normal n.x, n.y as signed 16-bit fractions of
+                           //    32767 (low, high); y: n.z (low), spread as half (high)
   int32_t link[BVH_WIDTH]; // as BvhNode: >= 0 child node, < 0 leaf ~(slot << 3),
                            // BVH_EMPTY none
+  int32_t pad[4];
+};
+
+// A leaf's triangle: what maths.cpp:64-119 reads, in one 64-byte half line.
+struct alignas(64) TriLeaf {
+  float4 n_d;  // N.xyz, d = N.p1 (as TriRec)
+  float4 a;    // p1.xyz, p2.x
+  float4 b;    // p2.yz, p3.xy
+  float4 c;    // p3.z, bits of the triangle's index, 0, 0
 };
 
 struct TriBvhHost {

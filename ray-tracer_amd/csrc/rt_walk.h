@@ -26,7 +26,6 @@
 
 namespace rt {
 
-constexpr int WALK_FETCH_AT = 16; // refill when this many lanes have nothing to do
 
 // Tests every triangle for one lane's ray (renderer.cpp:156-166).
 __device__ __forceinline__ void lane_triangles(const SceneDev &sc, bool any_hit, float ox,
@@ -131,14 +130,13 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   // exact test of leaf `slot` for this lane's ray, folded into its nearest hit
   auto leaf = [&](int slot) -> bool {
     if (TRI)
-      return tri_fold(sc.tleaf[slot], sc.tleaf_idx[slot], ox, oy, oz, dx, dy, dz, len_s, idx_s,
-                      sPx, sPy, sPz);
+      return tri_fold_leaf(sc.tleaf[slot], ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy, sPz);
     return leaf_test(sc, slot, a, a4, ox, oy, oz, dx, dy, dz, len_s, idx_s, sPx, sPy, sPz);
   };
 
   while (true) {
     const int n_free = __builtin_popcountll(__ballot(state != BUSY));
-    if (n_free == 64 || (!drained && n_free >= WALK_FETCH_AT)) {
+    if (n_free == 64 || (!drained && n_free >= w.fetch_at)) {
       // ---- work off parked leaves, all lanes together ----
       while (__any(n_park > 0)) {
         if (n_park > 0) {
@@ -279,8 +277,8 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
           links[c] = N.link[c];
           nears[c] = RT_INF;
           touch[c] = links[c] != BVH_EMPTY &&
-                     tri_touches(N.s[c], N.n[c], N.spread[c], ox, oy, oz, dx, dy, dz, a, da, ol,
-                                 bound, nears[c]);
+                     tri_touches(N.s[c], N.ns[c], ox, oy, oz, dx, dy, dz, a, da, ol, bound,
+                                 nears[c]);
         }
       } else {
         const BvhNode N = sc.bvh[node];

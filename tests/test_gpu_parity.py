@@ -262,7 +262,7 @@ def test_screen_never_drops_a_candidate(name, w, h):
     else:
         sc = golden_scenes.full_frame_scenes()[name]
     fb = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
-    stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+    stats = torch.zeros(16, dtype=torch.int64, device="cuda")
     with rtamd.DeviceScene(sc) as ds:
         ds.render_device(fb.data_ptr(), None, w, h, dev_selfcheck_stats=stats.data_ptr())
         torch.cuda.synchronize()

@@ -8,7 +8,7 @@ import torch, rtamd, bench
 name = sys.argv[1] if len(sys.argv) > 1 else "10k-spheres-4k-depth8"
 sc, w, h, depth = bench.build_scene(name)
 fb = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
-stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+stats = torch.zeros(16, dtype=torch.int64, device="cuda")
 cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
 with rtamd.DeviceScene(sc) as ds:
     ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth, dev_ray_count=cnt.data_ptr(),
@@ -16,6 +16,7 @@ with rtamd.DeviceScene(sc) as ds:
     torch.cuda.synchronize()
 s = [int(x) for x in stats.cpu()]
 print("rays", int(cnt.item()), "screen: dropped-but-candidate", s[0], "kept", s[1])
-for label, o in (("nearest", 2), ("shadow", 5)):
+for label, o in (("spheres nearest", 2), ("spheres shadow", 5), ("triangles nearest", 8),
+                 ("triangles shadow", 11)):
     r = max(1, s[o])
-    print(f"{label}: walks {s[o]}  node bounds/ray {s[o+1]/r:.1f}  leaf spheres/ray {s[o+2]/r:.2f}")
+    print(f"{label}: walks {s[o]}  child bounds/ray {s[o+1]/r:.1f}  leaf tests/ray {s[o+2]/r:.2f}")
