@@ -31,6 +31,7 @@ WORKLOADS = {
     # name: (grid rows, grid cols, width, height, depth, materials, mesh quads or None)
     "10k-spheres-4k-depth8": (100, 100, 3840, 2160, 8, True, None),
     "10k-spheres-4k-depth1": (100, 100, 3840, 2160, 1, False, None),
+    "10k-spheres-8k-depth8": (100, 100, 7680, 4320, 8, True, None),
     "1k-spheres-1080p-depth4": (32, 32, 1920, 1080, 4, True, None),
     "1k-spheres-1080p-depth1": (32, 32, 1920, 1080, 1, False, None),
     "shipped-1440p-depth1": (10, 10, 2560, 1440, 1, False, None),

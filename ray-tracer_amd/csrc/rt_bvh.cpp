@@ -1,6 +1,6 @@
-// rt_bvh.cpp — host-side construction of the bounding-sphere hierarchy
-// (two rounds of median splits on the longest axis of the centres' bounding
-// box per node: up to four children; one sphere per leaf).
+// rt_bvh.cpp — host-side construction of the sphere hierarchy (two rounds of
+// median splits on the longest axis of the centres' bounding box per node: up
+// to four children; one sphere per leaf; children bounded by boxes).
 #include "rt_bvh.h"
 
 #include <algorithm>
@@ -16,47 +16,60 @@ struct Builder {
   std::vector<int32_t> order;
   BvhHost *out;
 
-  // Smallest float >= x.
+  // Smallest float >= x / largest float <= x.
   static float round_up(double x) {
     float f = (float)x;
     if ((double)f < x)
       f = std::nextafter(f, INFINITY);
     return f;
   }
-
-  // Bounding sphere of order[b, e): centre of the centres' box, radius covering
-  // every member sphere entirely, rounded outwards.
-  float4 bound(int b, int e, int &axis) const {
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = b; k < e; k++)
-      for (int d = 0; d < 3; d++) {
-        double v = c[3 * order[k] + d];
-        lo[d] = std::min(lo[d], v);
-        hi[d] = std::max(hi[d], v);
-      }
-    double mid[3];
-    axis = 0;
-    for (int d = 0; d < 3; d++) {
-      mid[d] = 0.5 * (lo[d] + hi[d]);
-      if (hi[d] - lo[d] > hi[axis] - lo[axis])
-        axis = d;
-    }
-    float cf[3] = {(float)mid[0], (float)mid[1], (float)mid[2]};
-    double R = 0;
-    for (int k = b; k < e; k++) {
-      const float *p = c + 3 * order[k];
-      double dx = p[0] - (double)cf[0], dy = p[1] - (double)cf[1], dz = p[2] - (double)cf[2];
-      R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)r[order[k]]));
-    }
-    return make_float4(cf[0], cf[1], cf[2], round_up(R * (1.0 + 1e-6)));
-  }
-
-  static float near_bound(float4 s) {
-    double d = std::sqrt((double)s.x * s.x + (double)s.y * s.y + (double)s.z * s.z) - (double)s.w;
-    float f = (float)(d * (d > 0 ? 1.0 - 1e-6 : 1.0 + 1e-6));
-    if ((double)f > d)
+  static float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x)
       f = std::nextafter(f, -INFINITY);
     return f;
+  }
+
+  struct Box {
+    float lo[3], hi[3];
+  };
+
+  // Box of order[b, e) covering every member sphere entirely, rounded outwards;
+  // axis = longest axis of the centres' box.
+  Box bound(int b, int e, int &axis) const {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = b; k < e; k++) {
+      const double rad = std::fabs((double)r[order[k]]) * (1.0 + 1e-6);
+      for (int d = 0; d < 3; d++) {
+        const double v = c[3 * order[k] + d];
+        clo[d] = std::min(clo[d], v);
+        chi[d] = std::max(chi[d], v);
+        lo[d] = std::min(lo[d], v - rad);
+        hi[d] = std::max(hi[d], v + rad);
+      }
+    }
+    axis = 0;
+    for (int d = 1; d < 3; d++)
+      if (chi[d] - clo[d] > chi[axis] - clo[axis])
+        axis = d;
+    Box B;
+    for (int d = 0; d < 3; d++) {
+      B.lo[d] = round_down(lo[d]);
+      B.hi[d] = round_up(hi[d]);
+    }
+    return B;
+  }
+
+  // distance from the world origin to the box, rounded down
+  static float near_bound(const Box &B) {
+    double s2 = 0;
+    for (int d = 0; d < 3; d++) {
+      const double g = B.lo[d] > 0 ? B.lo[d] : (B.hi[d] < 0 ? -(double)B.hi[d] : 0.0);
+      s2 += g * g;
+    }
+    const double dist = std::sqrt(s2);
+    return round_down(dist * (1.0 - 1e-6));
   }
 
   void split(int b, int e, int &m) {
@@ -70,10 +83,25 @@ struct Builder {
                      });
   }
 
-  // Returns the link for order[b, e) and its bounding sphere.
-  int32_t build(int b, int e, float4 &sphere) {
+  static void store(BvhNode &N, int k, const Box &B, int32_t link, bool present) {
+    union {
+      int32_t i;
+      float f;
+    } bits;
+    bits.i = link;
+    if (present) {
+      N.a[k] = make_float4(B.lo[0], B.lo[1], B.lo[2], B.hi[0]);
+      N.b[k] = make_float4(B.hi[1], B.hi[2], near_bound(B), bits.f);
+    } else {
+      N.a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      N.b[k] = make_float4(0.f, 0.f, INFINITY, bits.f);
+    }
+  }
+
+  // Returns the link for order[b, e) and its box.
+  int32_t build(int b, int e, Box &box) {
     int axis;
-    sphere = bound(b, e, axis);
+    box = bound(b, e, axis);
     const int n = e - b;
     if (n == 1) {
       const int slot = (int)out->leaf_idx.size();
@@ -81,7 +109,6 @@ struct Builder {
       return ~(slot << 3);
     }
     // two median splits: up to four parts
-    int cut[5] = {b, b, b, b, e};
     int m;
     split(b, e, m);
     int parts = 0;
@@ -101,25 +128,15 @@ struct Builder {
         hi[parts++] = he;
       }
     }
-    (void)cut;
     const int me = (int)out->nodes.size();
     out->nodes.push_back(BvhNode{});
-    float4 cs[BVH_WIDTH];
+    Box cs[BVH_WIDTH];
     int32_t cl[BVH_WIDTH];
-    for (int k = 0; k < BVH_WIDTH; k++) {
-      if (k < parts) {
-        cl[k] = build(lo[k], hi[k], cs[k]);
-      } else {
-        cl[k] = BVH_EMPTY;
-        cs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+    for (int k = 0; k < BVH_WIDTH; k++)
+      cl[k] = k < parts ? build(lo[k], hi[k], cs[k]) : BVH_EMPTY;
     BvhNode &N = out->nodes[me];
-    for (int k = 0; k < BVH_WIDTH; k++) {
-      N.s[k] = cs[k];
-      N.link[k] = cl[k];
-      N.near[k] = k < parts ? near_bound(cs[k]) : INFINITY;
-    }
+    for (int k = 0; k < BVH_WIDTH; k++)
+      store(N, k, cs[k], cl[k], k < parts);
     return me;
   }
 };
@@ -145,17 +162,14 @@ void bvh_build(const float *spheres, const float *radius, int n, BvhHost &out) {
   std::iota(B.order.begin(), B.order.end(), 0);
   B.out = &out;
   out.leaf_idx.reserve(n);
-  float4 root;
+  Builder::Box root;
   // node 0 is always the root; a one-sphere scene still gets a node
   if (n == 1) {
     out.nodes.push_back(BvhNode{});
     int32_t l = B.build(0, 1, root);
     BvhNode &N = out.nodes[0];
-    for (int k = 0; k < BVH_WIDTH; k++) {
-      N.s[k] = root;
-      N.link[k] = k == 0 ? l : BVH_EMPTY;
-      N.near[k] = k == 0 ? -INFINITY : INFINITY;
-    }
+    for (int k = 0; k < BVH_WIDTH; k++)
+      Builder::store(N, k, root, k == 0 ? l : BVH_EMPTY, k == 0);
   } else {
     int32_t l = B.build(0, n, root);
     (void)l; // == 0: the first node pushed

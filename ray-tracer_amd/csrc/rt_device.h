@@ -346,42 +346,65 @@ struct ScreenStats { // filled only by the verification build of the kernels
 #define RT_BEAM_APEX 1
 #define RT_ACCEL_BVH 3
 
-// Can the line {o + t d} touch any sphere inside the bounding sphere s?  Must
-// say yes whenever the float discriminant test (maths.cpp:132-133) can pass for
-// a member sphere (centre c, radius r) of the node.  From the bound above,
+// Can the line {o + t d} touch any sphere inside the box [lo, hi] of a child
+// (a = lo.xyz, hi.x; b = hi.yz, near, link)?  Must say yes whenever the float
+// discriminant test (maths.cpp:132-133) can pass for a member sphere (centre c,
+// radius r, entirely inside the box).  From the bound above,
 //   dist(c, line) <= r sqrt(1+64u) + sqrt(64u) |o - c|,  sqrt(64u) = 2^-9,
-// and |o - c| <= |M| + R, |c - centre| + r <= R with M = centre - o, so
-//   dist(centre, line) <= R (1 + 2^-9 + 2^-18) + 2^-9 |M|  =: Rtot.
-// dist^2 * a = a |M|^2 - (M.d)^2 is formed with |M|^2 deflated by (1-2^-19),
-// which exceeds the rounding of its five products and sums (and of using the
-// float a for |d|^2); Rtot is rounded outwards through its two coefficients.
-// NaN or inf anywhere answers yes.
+// and |o - c| <= S1 := sum over the axes of max(|lo - o|, |hi - o|), r <= S1 / 3,
+// so the line passes within 0.002 S1 of the box, i.e. through the box grown by
+// m = 0.0021 S1 on every side (the extra 1e-4 S1 is thousands of times the
+// rounding of the slab arithmetic below).  The slab test keeps the child unless
+// the entry parameter exceeds the exit parameter by more than 2^-20 of their
+// magnitudes (each carries <= 4u relative error).  ix, iy, iz = 1/d per axis:
+// a zero component gives +-inf, the slab then constrains nothing when o lies
+// inside it and rejects when o lies outside; NaN (0 x inf, inf - inf) answers
+// yes, except for a line exactly in a face plane of the grown box, which cannot
+// belong to a candidate (the true margin is strictly smaller).
 //
-// Two more ways out, both one-sided:
-//  - the node lies behind the ray origin: (C - o).d/|d| + R < -mu with
-//    mu = 2^-8 (|M| + R).  Then for every member sphere d.L > 0 and
-//    |L|^2 - r^2 > 0 by margins thousands of times their rounding, so
+// Two more ways out, both one-sided, with mu = 0.0045 S1 > 2^-8 (|o - c| + r):
+//  - the grown box lies behind the ray origin by more than mu: its exit
+//    parameter is below -mu / |d| (ida >= 1/|d|).  Every member's closest
+//    approach and roots lie inside the box's parameter range, so d.L > mu |d|
+//    and |L|^2 - r^2 > mu^2, margins thousands of times their rounding:
 //    maths.cpp:138-152 computes two negative roots and reports no hit;
-//  - every point of the node is farther from the world origin than `bound`
+//  - every point of the box is farther from the world origin than `bound`
 //    (the best |P| so far): near - mu > bound.  A reported P is within mu of the
 //    sphere it belongs to even when the roots are ill-conditioned (the
 //    discriminant carries an absolute error <= 17u (2|d||L|)^2, i.e. <= 1e-3 |L|
-//    on the roots), so such a node cannot supply a nearer hit.  Ties are kept:
+//    on the roots), so such a child cannot supply a nearer hit.  Ties are kept:
 //    the comparison is strict.
-__device__ __forceinline__ bool bvh_touches(float4 s, float near, float ox, float oy,
-                                            float oz, float dx, float dy, float dz,
-                                            float a, float da, float bound) {
-  float Mx = s.x - ox, My = s.y - oy, Mz = s.z - oz;
-  float m2 = fmaf(Mz, Mz, fmaf(My, My, Mx * Mx));
-  float md = fmaf(dz, Mz, fmaf(dy, My, dx * Mx));
-  float mlen = __builtin_amdgcn_sqrtf(m2);
-  float Rtot = fmaf(s.w, 1.002f, mlen * 0.00196f);
-  float lhs = fmaf(-md, md, (a * m2) * 0.99999809265136719f);
-  float rhs = (a * Rtot) * (Rtot * 1.000001f);
-  float mu = fmaf(mlen, 0.0040f, s.w * 0.0040f); // > 2^-8 (|M| + R)
-  bool behind = fmaf(da, s.w + mu, md) < 0.f;
-  bool far = (near - mu) > bound;
-  return !(lhs > rhs) && !behind && !far;
+__device__ __forceinline__ bool bvh_touches(float4 a, float4 b, float ox, float oy, float oz,
+                                            float ix, float iy, float iz, float ida,
+                                            float bound) {
+  const float ax = a.x - ox, ay = a.y - oy, az = a.z - oz;
+  const float bx = a.w - ox, by = b.x - oy, bz = b.y - oz;
+  const float S1 = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) +
+                   fmaxf(fabsf(az), fabsf(bz));
+  const float m = S1 * 0.0021f;
+  const float t0x = (ax - m) * ix, t1x = (bx + m) * ix;
+  const float t0y = (ay - m) * iy, t1y = (by + m) * iy;
+  const float t0z = (az - m) * iz, t1z = (bz + m) * iz;
+  const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+  const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+  const bool miss = (tmin - tmax) > 9.5367431640625e-07f * (fabsf(tmin) + fabsf(tmax));
+  const float mu = S1 * 0.0045f;
+  const bool behind = tmax < -(mu * ida);
+  const bool far = (b.z - mu) > bound;
+  return !miss && !behind && !far;
+}
+
+// Per-ray constants of the sphere walk: 1/d per axis and an upper bound of 1/|d|.
+struct SphWalkRay {
+  float ix, iy, iz, ida;
+};
+__device__ __forceinline__ SphWalkRay sph_walk_ray(float dx, float dy, float dz, float a) {
+  SphWalkRay r;
+  r.ix = 1.0f / dx;
+  r.iy = 1.0f / dy;
+  r.iz = 1.0f / dz;
+  r.ida = __builtin_amdgcn_rsqf(a) * 1.001f;
+  return r;
 }
 
 // ---- the triangle hierarchy (rt_tribvh.h) ------------------------------------------
@@ -701,7 +724,7 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
         int node = 0;
         bool done = false;
         unsigned n_nodes = 0, n_leaf = 0;
-        const float da = sqrtf(a) * 1.000244140625f; // >= |d|
+        const SphWalkRay wr = sph_walk_ray(dx, dy, dz, a);
         // a sphere can only win against the nearest triangle by being strictly
         // nearer (renderer.cpp:181)
         float bound = ANY_HIT ? RT_INF : len_t;
@@ -712,18 +735,18 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
           float next_near = RT_INF;
 #pragma unroll
           for (int c = 0; c < BVH_WIDTH; c++) {
-            const int32_t link = N.link[c];
+            const int32_t link = __float_as_int(N.b[c].w);
             if (link == BVH_EMPTY ||
-                !bvh_touches(N.s[c], N.near[c], ox, oy, oz, dx, dy, dz, a, da, bound))
+                !bvh_touches(N.a[c], N.b[c], ox, oy, oz, wr.ix, wr.iy, wr.iz, wr.ida, bound))
               continue;
             if (link >= 0) {
               // keep the child nearest to the world origin for the next visit (it
               // tightens `bound`), stack the others
               int push = link;
-              if (N.near[c] < next_near) {
+              if (N.b[c].z < next_near) {
                 push = next;
                 next = link;
-                next_near = N.near[c];
+                next_near = N.b[c].z;
               }
               if (push >= 0 && sp < BVH_STACK)
                 stack[sp++] = push;

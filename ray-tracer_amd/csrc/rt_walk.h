@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   int state = EMPTY;
   uint32_t ray = 0, tagA = 0, tagB = 0;
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, a = 0, a4 = 0, da = 0, ol = 0;
+  float ix = 0, iy = 0, iz = 0; // spheres: 1/d per axis; `da` then holds >= 1/|d|
   float len_s = RT_INF, bound = RT_INF;
   int idx_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
@@ -224,7 +225,11 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
               } else {
                 a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
                 a4 = 4.0f * a;
-                da = __builtin_amdgcn_sqrtf(a) * 1.001f; // >= |d|
+                const SphWalkRay wr = sph_walk_ray(dx, dy, dz, a);
+                ix = wr.ix;
+                iy = wr.iy;
+                iz = wr.iz;
+                da = wr.ida;
                 // a sphere only matters if it is strictly nearer than the ray's
                 // nearest triangle (renderer.cpp:181)
                 if (!ANY_HIT && w.prior.idx != nullptr && w.prior.idx[seg_base + r] >= 0)
@@ -284,10 +289,10 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
         const BvhNode N = sc.bvh[node];
 #pragma unroll
         for (int c = 0; c < BVH_WIDTH; c++) {
-          links[c] = N.link[c];
-          nears[c] = N.near[c];
+          links[c] = __float_as_int(N.b[c].w);
+          nears[c] = N.b[c].z;
           touch[c] = links[c] != BVH_EMPTY &&
-                     bvh_touches(N.s[c], N.near[c], ox, oy, oz, dx, dy, dz, a, da, bound);
+                     bvh_touches(N.a[c], N.b[c], ox, oy, oz, ix, iy, iz, da, bound);
         }
       }
 #pragma unroll
