@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--screen", choices=["auto", "off", "beam", "bvh"], default="auto",
                     help="work avoidance mode (rt_set_screen); off = plain every-ray-"
                          "every-sphere loop")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="sub-frames in flight inside one rt_render_device call (rt_set_lanes)")
     args = ap.parse_args()
 
     import torch
@@ -142,6 +144,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ds = rtamd.DeviceScene(sc)
     rtamd.set_screen(args.screen)
+    if args.lanes is not None:
+        rtamd.lib().rt_set_lanes(args.lanes)
     send, recv = plan.alloc_gather(comm_dev)
     # A second frame buffer lets the gather of frame k overlap the render of
     # frame k+1 (the gather runs on the communicator's own stream).

@@ -157,6 +157,15 @@ int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
 void rt_set_screen(int mode);
 int rt_get_screen(void);
 
+/* A frame with bounces (max_depth > 1) can be rendered as n independent
+ * sub-frames of alternate row bands, each a chain of launches on its own stream
+ * with its own queues.  n = 1..4, default 1 (more chains were measured to bring
+ * no gain on this chip: the walk kernels are bound by instruction issue).
+ * Results do not depend on n.  No counterpart in the reference.  Process-wide,
+ * like rt_set_screen.                                                         */
+void rt_set_lanes(int n);
+int rt_get_lanes(void);
+
 /* As rt_render_device, with a slow self-checking build of the kernel that
  * re-tests every sphere the screen dropped.  dev_stats (device, 16 x uint64,
  * zeroed by the caller) receives

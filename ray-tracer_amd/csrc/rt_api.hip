@@ -60,6 +60,48 @@ template <typename T> struct DevBuf {
 
 } // namespace
 
+// A frame with bounces can be rendered as several independent sub-frames
+// (alternate row bands), each a chain of dependent launches on its own stream
+// with its own queues (rt_set_lanes).  Measured on the 10k-sphere 4K depth-8
+// frame the chains do run concurrently (kernel trace) but the walk kernels are
+// bound by instruction issue, not by idle tails, so nothing is gained: 8.78 ms
+// with 1 lane, 8.80 with 2, 9.92 with 3, 9.69 with 4; 1 is the default.
+constexpr int kMaxLanes = 4;
+int g_lanes = 1;
+
+struct BounceLane {
+  DevBuf<float4> queue[2];
+  // control words.  A "row" is one counter per queue segment (QUEUE_SEGMENTS x
+  // CTL_WORDS uint32).  Per level: rows {queue length, sphere-walk cursor,
+  // triangle-walk cursor}, then per group of lights {shadow items, sphere-walk
+  // cursor, triangle-walk cursor}; the very last word is the overflow flag
+  DevBuf<uint32_t> counts;
+  int ctl_rows = 0; // rows per level
+  DevBuf<float4> hit_rec, tri_hit_rec, shadow_items[2]; // shadow items: by level parity
+  DevBuf<int32_t> hit_idx, tri_hit_idx;
+  size_t queue_capacity = 0;
+  // The shadow walks of level L and the nearest-hit walks of level L+1 both
+  // depend only on k_shade of level L, so the shadow walks run on a side stream.
+  hipStream_t main = nullptr; // lanes >= 1; lane 0 runs on the caller's stream
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_end = nullptr;
+
+  ~BounceLane() {
+    for (int k = 0; k < 2; k++) {
+      if (ev_fork[k])
+        (void)hipEventDestroy(ev_fork[k]);
+      if (ev_join[k])
+        (void)hipEventDestroy(ev_join[k]);
+    }
+    if (ev_end)
+      (void)hipEventDestroy(ev_end);
+    if (side)
+      (void)hipStreamDestroy(side);
+    if (main)
+      (void)hipStreamDestroy(main);
+  }
+};
+
 struct rt_scene {
   int device = 0;
   int t_size = 0, s_size = 0, s_pad = 0, l_size = 0;
@@ -78,17 +120,15 @@ struct rt_scene {
   bool eye_valid = false;
   float eye[3] = {0, 0, 0};
   // bounce machinery, allocated on the first max_depth > 1 render
-  DevBuf<float4> queue[2];
-  // control words.  A "row" is one counter per queue segment (QUEUE_SEGMENTS x
-  // CTL_WORDS uint32).  Per level: rows {queue length, sphere-walk cursor,
-  // triangle-walk cursor}, then per group of lights {shadow items, sphere-walk
-  // cursor, triangle-walk cursor}; the very last word is the overflow flag
-  DevBuf<uint32_t> counts;
-  int ctl_rows = 0; // rows per level
+  BounceLane lanes[kMaxLanes];
   DevBuf<unsigned long long> extra; // per pixel, 3 x 21 bits
-  DevBuf<float4> hit_rec, tri_hit_rec, shadow_items;
-  DevBuf<int32_t> hit_idx, tri_hit_idx;
-  size_t queue_capacity = 0, extra_pixels = 0;
+  size_t extra_pixels = 0;
+  hipEvent_t ev_begin = nullptr;
+
+  ~rt_scene() {
+    if (ev_begin)
+      (void)hipEventDestroy(ev_begin);
+  }
 
   rt::SceneDev dev() const {
     rt::SceneDev d;
@@ -289,26 +329,39 @@ constexpr int kLightGroup = 4; // lights whose shadow rays share one pass
 constexpr int kLevels = 66; // levels 0..65 (depth <= 63, +1 for the last spawn target)
 constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
 
-int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels) {
+int ensure_bounce_buffers(rt_scene *S, BounceLane *B, bool own_stream, size_t frame_pixels,
+                          size_t owned_pixels) {
   size_t want = 4 * owned_pixels + 65536;
   if (want > 0x0ffffff0ull)
     want = 0x0ffffff0ull;
   want = (want + rt::QUEUE_SEGMENTS - 1) / rt::QUEUE_SEGMENTS * rt::QUEUE_SEGMENTS;
-  if (S->queue_capacity < want) {
+  if (B->queue_capacity < want) {
     for (int q = 0; q < 2; q++)
-      HIP_TRY(S->queue[q].alloc(2 * want));
-    HIP_TRY(S->hit_rec.alloc(want));
-    HIP_TRY(S->hit_idx.alloc(want));
+      HIP_TRY(B->queue[q].alloc(2 * want));
+    HIP_TRY(B->hit_rec.alloc(want));
+    HIP_TRY(B->hit_idx.alloc(want));
     if (S->has_tbvh) {
-      HIP_TRY(S->tri_hit_rec.alloc(want));
-      HIP_TRY(S->tri_hit_idx.alloc(want));
+      HIP_TRY(B->tri_hit_rec.alloc(want));
+      HIP_TRY(B->tri_hit_idx.alloc(want));
     }
-    HIP_TRY(S->shadow_items.alloc(2 * want * kLightGroup));
-    S->queue_capacity = want;
+    const int per_ray = S->l_size < kLightGroup ? (S->l_size > 0 ? S->l_size : 1) : kLightGroup;
+    for (int k = 0; k < 2; k++)
+      HIP_TRY(B->shadow_items[k].alloc(2 * want * per_ray));
+    B->queue_capacity = want;
   }
-  if (!S->counts.p) {
-    S->ctl_rows = 3 + 3 * ((S->l_size + kLightGroup - 1) / kLightGroup + 1);
-    HIP_TRY(S->counts.alloc((size_t)kLevels * S->ctl_rows * kRowWords + 1));
+  if (!B->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(hipEventCreateWithFlags(&B->ev_fork[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&B->ev_join[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&B->ev_end, hipEventDisableTiming));
+  }
+  if (own_stream && !B->main)
+    HIP_TRY(hipStreamCreateWithFlags(&B->main, hipStreamNonBlocking));
+  if (!B->counts.p) {
+    B->ctl_rows = 3 + 3 * ((S->l_size + kLightGroup - 1) / kLightGroup + 1);
+    HIP_TRY(B->counts.alloc((size_t)kLevels * B->ctl_rows * kRowWords + 1));
   }
   if (S->extra_pixels < frame_pixels) {
     HIP_TRY(S->extra.alloc(frame_pixels));
@@ -318,19 +371,19 @@ int ensure_bounce_buffers(rt_scene *S, size_t frame_pixels, size_t owned_pixels)
   return RT_OK;
 }
 
-uint32_t *ctl(rt_scene *S, int level, int row) {
-  return S->counts.p + ((size_t)level * S->ctl_rows + row) * kRowWords;
+uint32_t *ctl(BounceLane *B, int level, int row) {
+  return B->counts.p + ((size_t)level * B->ctl_rows + row) * kRowWords;
 }
-uint32_t *overflow_flag(rt_scene *S) {
-  return S->counts.p + (size_t)kLevels * S->ctl_rows * kRowWords;
+uint32_t *overflow_flag(BounceLane *B) {
+  return B->counts.p + (size_t)kLevels * B->ctl_rows * kRowWords;
 }
 
-rt::RayQueue queue_for_level(rt_scene *S, int level) {
+rt::RayQueue queue_for_level(BounceLane *B, int level) {
   rt::RayQueue q;
-  q.items = S->queue[level & 1].p;
-  q.count = ctl(S, level, 0);
-  q.seg_capacity = (uint32_t)(S->queue_capacity / rt::QUEUE_SEGMENTS);
-  q.overflow = overflow_flag(S);
+  q.items = B->queue[level & 1].p;
+  q.count = ctl(B, level, 0);
+  q.seg_capacity = (uint32_t)(B->queue_capacity / rt::QUEUE_SEGMENTS);
+  q.overflow = overflow_flag(B);
   return q;
 }
 
@@ -391,6 +444,158 @@ int rt_scene_create(const scene_desc *scene, rt_scene **out) {
 
 void rt_scene_destroy(rt_scene *scene) { delete scene; }
 
+// One sub-frame: lane `lane` of `n_lanes`.  Lane 0 runs on the caller's stream,
+// the others on their own, started after everything the caller queued before.
+static int render_lane(rt_scene *S, int lane, int n_lanes, const camera *cam, const rt_frame *fr,
+                       int band_rows, int band_count, bool bounces, hipStream_t caller,
+                       uint64_t *dev_ray_count, uint64_t *dev_verify) {
+  BounceLane *B = &S->lanes[lane];
+  const int sub_index = fr->band_index + lane * band_count;
+  const int sub_count = band_count * n_lanes;
+  rt::FrameDev f;
+  f.fb = fr->dev_fb;
+  f.ids = fr->dev_ids;
+  f.ray_count = dev_ray_count;
+  f.w = fr->w;
+  f.h = fr->h;
+  f.max_depth = fr->max_depth;
+  f.band_rows = band_rows;
+  f.band_index = sub_index;
+  f.band_count = sub_count;
+  int bands_total = (fr->h + band_rows - 1) / band_rows;
+  int owned = bands_total > sub_index ? (bands_total - sub_index + sub_count - 1) / sub_count : 0;
+  const int owned_tile_rows = owned * (band_rows / 8);
+  rt::BounceDev bd;
+  memset(&bd, 0, sizeof bd);
+  bd.max_depth = 1;
+  hipStream_t st = caller;
+  int rc;
+  if (bounces) {
+    rc = ensure_bounce_buffers(S, B, lane > 0, (size_t)fr->w * fr->h,
+                               (size_t)owned_tile_rows * 8 * fr->w);
+    if (rc)
+      return rc;
+    if (lane > 0) {
+      st = B->main;
+      HIP_TRY(hipStreamWaitEvent(st, S->ev_begin, 0));
+    }
+    // only the levels this frame can reach, and the overflow flag
+    HIP_TRY(hipMemsetAsync(B->counts.p, 0,
+                           (size_t)(fr->max_depth + 2) * B->ctl_rows * kRowWords * sizeof(uint32_t),
+                           st));
+    HIP_TRY(hipMemsetAsync(overflow_flag(B), 0, sizeof(uint32_t), st));
+    bd.max_depth = fr->max_depth;
+    bd.extra = S->extra.p;
+    bd.out = queue_for_level(B, 2);
+  }
+  const rt::SceneDev sd = S->dev();
+  // 0 plain loop, 1 automatic (hierarchy when the scene has one, else the beam
+  // screen), 2 beam screen, 3 hierarchy
+  int accel = RT_BEAM_NONE;
+  if (g_screen == 2 || ((g_screen == 1 || g_screen == 3) && !S->has_bvh))
+    accel = RT_BEAM_APEX;
+  else if (g_screen == 1 || g_screen == 3)
+    accel = RT_ACCEL_BVH;
+  HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, owned_tile_rows,
+                            accel, (unsigned long long *)dev_verify, st));
+  if (bounces) {
+    // With a sphere hierarchy each level runs as walk / shade / shadow-walk
+    // launches with dynamic ray fetch (rt_walk.h); otherwise, or in the
+    // self-checking build, as one k_bounce launch per level.
+    const bool stream_levels = (sd.bvh != nullptr || sd.tbvh != nullptr) && !dev_verify;
+    const bool tri_walks = sd.tbvh != nullptr;
+    bool joined[2] = {false, false};
+    for (int level = 2; level <= fr->max_depth; level++) {
+      bd.in = queue_for_level(B, level);
+      bd.out = queue_for_level(B, level + 1);
+      if (!stream_levels) {
+        HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count,
+                                  (unsigned long long *)dev_verify, kBounceBlocks, st));
+        continue;
+      }
+      rt::HitList hl, tl;
+      hl.rec = B->hit_rec.p;
+      hl.idx = B->hit_idx.p;
+      tl.rec = tri_walks ? B->tri_hit_rec.p : nullptr;
+      tl.idx = tri_walks ? B->tri_hit_idx.p : nullptr;
+      rt::WalkArgs wa;
+      memset(&wa, 0, sizeof wa);
+      wa.fetch_at = rt::WALK_FETCH_AT;
+      wa.in = bd.in;
+      wa.extra = S->extra.p;
+      // each ray is counted once, by the first walk it goes through
+      if (tri_walks) {
+        wa.cursor = ctl(B, level, 2);
+        wa.hits = tl;
+        wa.ray_count = dev_ray_count;
+        HIP_TRY(rt::launch_walk(sd, wa, false, true, kBounceBlocks, st));
+        wa.prior = tl;
+      }
+      wa.cursor = ctl(B, level, 1);
+      wa.hits = hl;
+      wa.ray_count = tri_walks ? nullptr : dev_ray_count;
+      HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
+      rt::ShadeArgs sa;
+      memset(&sa, 0, sizeof sa);
+      sa.rays = bd.in;
+      sa.hits = hl;
+      sa.tri_hits = tl;
+      sa.max_depth = fr->max_depth;
+      sa.next = bd.out;
+      sa.ray_count = dev_ray_count;
+      const int n_groups = S->l_size > 0 ? (S->l_size + kLightGroup - 1) / kLightGroup : 1;
+      const int per_ray = S->l_size < kLightGroup ? (S->l_size > 0 ? S->l_size : 1) : kLightGroup;
+      // one group of lights: its shadow walks go to the side stream; more groups
+      // share the item buffer and stay in order on the caller's stream
+      const bool fork = n_groups == 1 && S->l_size > 0;
+      const int par = level & 1;
+      for (int g = 0; g < n_groups; g++) {
+        sa.light_begin = g * kLightGroup;
+        sa.light_end = S->l_size < (g + 1) * kLightGroup ? S->l_size : (g + 1) * kLightGroup;
+        sa.spawn = g == 0;
+        sa.shadow.items = B->shadow_items[fork ? par : 0].p;
+        sa.shadow.count = ctl(B, level, 3 + 3 * g);
+        sa.shadow.seg_capacity = bd.in.seg_capacity * per_ray;
+        sa.shadow.overflow = overflow_flag(B);
+        if (fork && joined[par]) // the shadow walk two levels up has read this buffer
+          HIP_TRY(hipStreamWaitEvent(st, B->ev_join[par], 0));
+        HIP_TRY(rt::launch_shade(sd, sa, kBounceBlocks, st));
+        if (S->l_size > 0) {
+          hipStream_t ws_stream = st;
+          if (fork) {
+            HIP_TRY(hipEventRecord(B->ev_fork[par], st));
+            HIP_TRY(hipStreamWaitEvent(B->side, B->ev_fork[par], 0));
+            ws_stream = B->side;
+          }
+          rt::WalkArgs ws;
+          memset(&ws, 0, sizeof ws);
+          ws.fetch_at = rt::WALK_FETCH_AT;
+          ws.in = sa.shadow;
+          ws.extra = S->extra.p;
+          if (tri_walks) {
+            ws.cursor = ctl(B, level, 5 + 3 * g);
+            ws.ray_count = dev_ray_count;
+            HIP_TRY(rt::launch_walk(sd, ws, true, true, kBounceBlocks, ws_stream));
+          }
+          ws.cursor = ctl(B, level, 4 + 3 * g);
+          ws.ray_count = tri_walks ? nullptr : dev_ray_count;
+          HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, ws_stream));
+          if (fork) {
+            HIP_TRY(hipEventRecord(B->ev_join[par], B->side));
+            joined[par] = true;
+          }
+        }
+      }
+    }
+    for (int k = 0; k < 2; k++)
+      if (joined[k])
+        HIP_TRY(hipStreamWaitEvent(st, B->ev_join[k], 0));
+    if (lane > 0)
+      HIP_TRY(hipEventRecord(B->ev_end, st));
+  }
+  return RT_OK;
+}
+
 static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr,
                               uint64_t *dev_ray_count, uint64_t *dev_verify) {
   if (!S || !cam || !fr)
@@ -418,122 +623,28 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
   int rc = scene_set_eye(S, cam, st);
   if (rc)
     return rc;
-
-  rt::FrameDev f;
-  f.fb = fr->dev_fb;
-  f.ids = fr->dev_ids;
-  f.ray_count = dev_ray_count;
-  f.w = fr->w;
-  f.h = fr->h;
-  f.max_depth = fr->max_depth;
-  f.band_rows = band_rows;
-  f.band_index = fr->band_index;
-  f.band_count = band_count;
-  int bands_total = (fr->h + band_rows - 1) / band_rows;
-  int owned = bands_total > fr->band_index
-                  ? (bands_total - fr->band_index + band_count - 1) / band_count
-                  : 0;
-  const int owned_tile_rows = owned * (band_rows / 8);
   // Bounces exist only where a material asks for them.
   const bool bounces = fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph);
-  rt::BounceDev bd;
-  memset(&bd, 0, sizeof bd);
-  bd.max_depth = 1;
-  if (bounces) {
-    rc = ensure_bounce_buffers(S, (size_t)fr->w * fr->h,
-                               (size_t)owned_tile_rows * 8 * fr->w);
+  int n_lanes = bounces && !dev_verify ? g_lanes : 1;
+  if (n_lanes < 1)
+    n_lanes = 1;
+  if (n_lanes > kMaxLanes)
+    n_lanes = kMaxLanes;
+  if (n_lanes > 1) {
+    if (!S->ev_begin)
+      HIP_TRY(hipEventCreateWithFlags(&S->ev_begin, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(S->ev_begin, st));
+  }
+  for (int k = 0; k < n_lanes; k++) {
+    // lane k renders bands band_index + k * band_count, stepping n_lanes * band_count
+    rc = render_lane(S, k, n_lanes, cam, fr, band_rows, band_count, bounces, st, dev_ray_count,
+                     dev_verify);
     if (rc)
       return rc;
-    // only the levels this frame can reach, and the overflow flag
-    HIP_TRY(hipMemsetAsync(S->counts.p, 0,
-                           (size_t)(fr->max_depth + 2) * S->ctl_rows * kRowWords * sizeof(uint32_t),
-                           st));
-    HIP_TRY(hipMemsetAsync(overflow_flag(S), 0, sizeof(uint32_t), st));
-    bd.max_depth = fr->max_depth;
-    bd.extra = S->extra.p;
-    bd.out = queue_for_level(S, 2);
   }
-  const rt::SceneDev sd = S->dev();
-  // 0 plain loop, 1 automatic (hierarchy when the scene has one, else the beam
-  // screen), 2 beam screen, 3 hierarchy
-  int accel = RT_BEAM_NONE;
-  if (g_screen == 2 || ((g_screen == 1 || g_screen == 3) && !S->has_bvh))
-    accel = RT_BEAM_APEX;
-  else if (g_screen == 1 || g_screen == 3)
-    accel = RT_ACCEL_BVH;
-  HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, owned_tile_rows,
-                            accel, (unsigned long long *)dev_verify, st));
   if (bounces) {
-    // With a sphere hierarchy each level runs as walk / shade / shadow-walk
-    // launches with dynamic ray fetch (rt_walk.h); otherwise, or in the
-    // self-checking build, as one k_bounce launch per level.
-    const bool stream_levels = (sd.bvh != nullptr || sd.tbvh != nullptr) && !dev_verify;
-    const bool tri_walks = sd.tbvh != nullptr;
-    for (int level = 2; level <= fr->max_depth; level++) {
-      bd.in = queue_for_level(S, level);
-      bd.out = queue_for_level(S, level + 1);
-      if (!stream_levels) {
-        HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count,
-                                  (unsigned long long *)dev_verify, kBounceBlocks, st));
-        continue;
-      }
-      rt::HitList hl, tl;
-      hl.rec = S->hit_rec.p;
-      hl.idx = S->hit_idx.p;
-      tl.rec = tri_walks ? S->tri_hit_rec.p : nullptr;
-      tl.idx = tri_walks ? S->tri_hit_idx.p : nullptr;
-      rt::WalkArgs wa;
-      memset(&wa, 0, sizeof wa);
-      wa.fetch_at = rt::WALK_FETCH_AT;
-      wa.in = bd.in;
-      wa.extra = S->extra.p;
-      // each ray is counted once, by the first walk it goes through
-      if (tri_walks) {
-        wa.cursor = ctl(S, level, 2);
-        wa.hits = tl;
-        wa.ray_count = dev_ray_count;
-        HIP_TRY(rt::launch_walk(sd, wa, false, true, kBounceBlocks, st));
-        wa.prior = tl;
-      }
-      wa.cursor = ctl(S, level, 1);
-      wa.hits = hl;
-      wa.ray_count = tri_walks ? nullptr : dev_ray_count;
-      HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
-      rt::ShadeArgs sa;
-      memset(&sa, 0, sizeof sa);
-      sa.rays = bd.in;
-      sa.hits = hl;
-      sa.tri_hits = tl;
-      sa.max_depth = fr->max_depth;
-      sa.next = bd.out;
-      sa.ray_count = dev_ray_count;
-      const int n_groups = S->l_size > 0 ? (S->l_size + kLightGroup - 1) / kLightGroup : 1;
-      for (int g = 0; g < n_groups; g++) {
-        sa.light_begin = g * kLightGroup;
-        sa.light_end = S->l_size < (g + 1) * kLightGroup ? S->l_size : (g + 1) * kLightGroup;
-        sa.spawn = g == 0;
-        sa.shadow.items = S->shadow_items.p;
-        sa.shadow.count = ctl(S, level, 3 + 3 * g);
-        sa.shadow.seg_capacity = bd.in.seg_capacity * kLightGroup;
-        sa.shadow.overflow = overflow_flag(S);
-        HIP_TRY(rt::launch_shade(sd, sa, kBounceBlocks, st));
-        if (S->l_size > 0) {
-          rt::WalkArgs ws;
-          memset(&ws, 0, sizeof ws);
-          ws.fetch_at = rt::WALK_FETCH_AT;
-          ws.in = sa.shadow;
-          ws.extra = S->extra.p;
-          if (tri_walks) {
-            ws.cursor = ctl(S, level, 5 + 3 * g);
-            ws.ray_count = dev_ray_count;
-            HIP_TRY(rt::launch_walk(sd, ws, true, true, kBounceBlocks, st));
-          }
-          ws.cursor = ctl(S, level, 4 + 3 * g);
-          ws.ray_count = tri_walks ? nullptr : dev_ray_count;
-          HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, st));
-        }
-      }
-    }
+    for (int k = 1; k < n_lanes; k++)
+      HIP_TRY(hipStreamWaitEvent(st, S->lanes[k].ev_end, 0));
     HIP_TRY(rt::launch_compose(fr->dev_fb, S->extra.p, (size_t)fr->w * fr->h, st));
   }
   return RT_OK;
@@ -555,15 +666,19 @@ int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {
   if (!S || !overflowed)
     return fail(RT_ERR_BAD_ARG, "scene or result is NULL");
   *overflowed = 0;
-  if (!S->counts.p)
-    return RT_OK;
-  uint32_t flag = 0;
   HIP_TRY(hipSetDevice(S->device));
-  HIP_TRY(hipMemcpy(&flag, overflow_flag(S), sizeof flag, hipMemcpyDeviceToHost));
-  *overflowed = flag != 0;
+  for (int k = 0; k < kMaxLanes; k++) {
+    if (!S->lanes[k].counts.p)
+      continue;
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, overflow_flag(&S->lanes[k]), sizeof flag, hipMemcpyDeviceToHost));
+    *overflowed |= flag != 0;
+  }
   return RT_OK;
 }
 
+void rt_set_lanes(int n) { g_lanes = n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n); }
+int rt_get_lanes(void) { return g_lanes; }
 void rt_set_screen(int enabled) { g_screen = enabled; }
 int rt_get_screen(void) { return g_screen; }
 

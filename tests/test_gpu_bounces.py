@@ -120,6 +120,23 @@ def test_screen_off_gives_the_same_bounces(oracle):
         assert np.array_equal(fb, fo) and n == no, mode
 
 
+def test_lane_count_does_not_change_the_frame(oracle):
+    """rt_set_lanes splits a bounce frame into sub-frames of alternate row bands
+    on separate streams; pixels, ids and ray counts must not depend on it."""
+    sc = material_scene(55, n_spheres=150, n_tris=6, n_lights=2)
+    fo, io, no = oracle.render(sc, 384, 216, max_depth=6)
+    try:
+        for lanes in (1, 2, 3, 4):
+            rtamd.lib().rt_set_lanes(lanes)
+            assert rtamd.lib().rt_get_lanes() == lanes
+            fb, ids, n = rtamd.render(sc, 384, 216, max_depth=6)
+            assert np.array_equal(ids, io), lanes
+            assert np.array_equal(fb, fo), lanes
+            assert n == no, lanes
+    finally:
+        rtamd.lib().rt_set_lanes(1)
+
+
 def test_invalid_materials_rejected():
     sc = golden_scenes.mixed_scene()
     sc.mat_sphere = np.zeros((sc.s_size, 4), np.float32)
