@@ -617,7 +617,8 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
 
   // ---- triangles, renderer.cpp:156-166 ----
-  if (sc.tbvh != nullptr) {
+  // (the plain-loop build carries no walk code: it is the brute-force yardstick)
+  if (BEAM != RT_BEAM_NONE && sc.tbvh != nullptr) {
     if (live)
       walk_triangles<ANY_HIT, VERIFY>(sc, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz,
                                       st.twalk);

@@ -607,7 +607,7 @@ hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st) 
   if (a.n <= 0)
     return hipSuccess;
   const dim3 grid((unsigned)((a.n + 255) / 256));
-  if (sc.bvh)
+  if (sc.bvh || sc.tbvh)
     hipLaunchKernelGGL((k_check<true>), grid, dim3(256), 0, st, sc, a);
   else
     hipLaunchKernelGGL((k_check<false>), grid, dim3(256), 0, st, sc, a);
