@@ -134,15 +134,9 @@ struct Builder {
     int32_t cl[BVH_WIDTH];
     for (int k = 0; k < BVH_WIDTH; k++)
       cl[k] = k < parts ? build(lo[k], hi[k], cs[k]) : BVH_EMPTY;
-    // children in ascending order of their distance bound from the world origin,
-    // absent ones last: a walk that pushes child 3, 2, 1, 0 then pops the nearest
-    // first without comparing anything
-    int ord[BVH_WIDTH] = {0, 1, 2, 3};
-    std::stable_sort(ord, ord + parts,
-                     [&](int x, int y) { return near_bound(cs[x]) < near_bound(cs[y]); });
     BvhNode &N = out->nodes[me];
     for (int k = 0; k < BVH_WIDTH; k++)
-      store(N, k, cs[ord[k]], cl[ord[k]], ord[k] < parts);
+      store(N, k, cs[k], cl[k], k < parts);
     return me;
   }
 };

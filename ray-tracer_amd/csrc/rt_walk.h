@@ -295,73 +295,41 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
                      bvh_touches(N.a[c], N.b[c], ox, oy, oz, ix, iy, iz, da, bound);
         }
       }
-      if (TRI) {
 #pragma unroll
-        for (int c = 0; c < BVH_WIDTH; c++) {
-          const int32_t link = links[c];
-          if (touch[c] && link < 0) {
-            // a touched leaf is parked (or, with four already parked, tested now)
-            const int slot = (~link) >> 3;
-            if (n_park < 4) {
-              if (n_park == 0)
-                p0 = slot;
-              else if (n_park == 1)
-                p1 = slot;
-              else if (n_park == 2)
-                p2 = slot;
-              else
-                p3 = slot;
-              n_park++;
-            } else if (leaf(slot)) {
-              if (!ANY_HIT)
-                bound = fminf(bound, len_s);
-            }
-          } else if (touch[c]) {
-            // visit the child with the smallest |P| bound next (it tightens
-            // `bound`), stack the others
-            int push = link;
-            if (nears[c] < next_near) {
-              push = next;
-              next = link;
-              next_near = nears[c];
-            }
-            if (push >= 0 && sp < BVH_STACK)
-              stack[sp++] = push;
+      for (int c = 0; c < BVH_WIDTH; c++) {
+        const int32_t link = links[c];
+        if (touch[c] && link < 0) {
+          // a touched leaf is parked (or, with four already parked, tested now)
+          const int slot = (~link) >> 3;
+          if (n_park < 4) {
+            if (n_park == 0)
+              p0 = slot;
+            else if (n_park == 1)
+              p1 = slot;
+            else if (n_park == 2)
+              p2 = slot;
+            else
+              p3 = slot;
+            n_park++;
+          } else if (leaf(slot)) {
+            if (!ANY_HIT)
+              bound = fminf(bound, len_s);
           }
-        }
-        if (next < 0 && sp > 0)
-          next = stack[--sp];
-      } else {
-        // the builder stores a node's children nearest-first (by their distance
-        // bound from the world origin): pushing 3, 2, 1, 0 pops the nearest first
-#pragma unroll
-        for (int c = BVH_WIDTH - 1; c >= 0; c--) {
-          const int32_t link = links[c];
-          if (touch[c] && link >= 0) {
-            if (sp < BVH_STACK)
-              stack[sp++] = link;
-          } else if (touch[c]) {
-            const int slot = (~link) >> 3;
-            if (n_park < 4) {
-              if (n_park == 0)
-                p0 = slot;
-              else if (n_park == 1)
-                p1 = slot;
-              else if (n_park == 2)
-                p2 = slot;
-              else
-                p3 = slot;
-              n_park++;
-            } else if (leaf(slot)) {
-              if (!ANY_HIT)
-                bound = fminf(bound, len_s);
-            }
+        } else if (touch[c]) {
+          // visit the child nearest to the world origin next (it tightens
+          // `bound`), stack the others
+          int push = link;
+          if (nears[c] < next_near) {
+            push = next;
+            next = link;
+            next_near = nears[c];
           }
+          if (push >= 0 && sp < BVH_STACK)
+            stack[sp++] = push;
         }
-        if (sp > 0)
-          next = stack[--sp];
       }
-      (void)next_near;
+      if (next < 0 && sp > 0)
+        next = stack[--sp];
       if (next >= 0 && !(ANY_HIT && idx_s >= 0))
         node = next;
       else
