@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
                 // nearest triangle (renderer.cpp:181)
                 if (!ANY_HIT && w.prior.idx != nullptr && w.prior.idx[seg_base + r] >= 0)
                   bound = w.prior.rec[seg_base + r].w;
+                // (Bounding the walk by the looped triangles' nearest hit as well was
+                // measured: the tests run on the few lanes that are refilling and cost
+                // more than the pruning saves, 9.27 ms against 8.76 ms per frame.)
                 const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
                 if (!(a > 0.f) || sc.s_size == 0) {
                   state = DRAIN; // no sphere can be hit (rt_device.h, beam screen notes)
