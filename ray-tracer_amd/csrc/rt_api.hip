@@ -12,7 +12,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <cstdlib>
 #include <new>
 
 #ifndef M_PI
@@ -23,8 +22,6 @@ namespace {
 
 thread_local char g_err[512] = "";
 int g_screen = 1; // rt_set_screen
-unsigned long long *g_dbg = nullptr;
-int g_dbg_level = 2;
 
 int fail(int code, const char *fmt, ...) {
   va_list ap;
@@ -524,8 +521,6 @@ static int render_lane(rt_scene *S, int lane, int n_lanes, const camera *cam, co
       rt::WalkArgs wa;
       memset(&wa, 0, sizeof wa);
       wa.fetch_at = rt::WALK_FETCH_AT;
-      wa.dbg = (g_dbg && level == g_dbg_level) ? g_dbg : nullptr;
-      wa.rays_per_lane = getenv("RT_RPL") ? atoi(getenv("RT_RPL")) : rt::WALK_RAYS_PER_LANE;
       wa.in = bd.in;
       wa.extra = S->extra.p;
       // each ray is counted once, by the first walk it goes through
@@ -575,7 +570,6 @@ static int render_lane(rt_scene *S, int lane, int n_lanes, const camera *cam, co
           rt::WalkArgs ws;
           memset(&ws, 0, sizeof ws);
           ws.fetch_at = rt::WALK_FETCH_AT;
-          ws.rays_per_lane = getenv("RT_RPL") ? atoi(getenv("RT_RPL")) : rt::WALK_RAYS_PER_LANE;
           ws.in = sa.shadow;
           ws.extra = S->extra.p;
           if (tri_walks) {
@@ -685,7 +679,6 @@ int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {
 
 void rt_set_lanes(int n) { g_lanes = n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n); }
 int rt_get_lanes(void) { return g_lanes; }
-void rt_debug_waves(unsigned long long *p, int level) { g_dbg = p; g_dbg_level = level; }
 void rt_set_screen(int enabled) { g_screen = enabled; }
 int rt_get_screen(void) { return g_screen; }
 

@@ -72,7 +72,6 @@ struct BounceDev {
 // Refill threshold: 4..48 measured on the 10k-sphere depth-8 frame, 11.98 ms at 4,
 // 10.72 at 16, 10.53 at 24, 10.66 at 48.
 constexpr int WALK_FETCH_AT = 24;
-constexpr int WALK_RAYS_PER_LANE = 8;
 struct WalkArgs {
   RayQueue in;        // items to walk: (origin, tagA bits), (direction, tagB bits)
   uint32_t *cursor;   // cursor[s * CTL_WORDS]: next item of segment s to hand out
@@ -81,8 +80,6 @@ struct WalkArgs {
   unsigned long long *extra; // shadow walks: tagA = pixel, tagB = packed integer
                              // light, added to the pixel if unoccluded
   uint64_t *ray_count;
-  unsigned long long *dbg;
-  int rays_per_lane;  // blocks beyond ceil(rays / (256 x this)) per segment exit at once
   int fetch_at;       // refill a wave when this many of its lanes have nothing to do
 };
 

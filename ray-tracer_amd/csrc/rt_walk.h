@@ -113,15 +113,6 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
     n_in = w.in.seg_capacity;
   const size_t seg_base = (size_t)seg * w.in.seg_capacity;
   uint32_t *const cursor = w.cursor + seg * CTL_WORDS;
-  // Surplus blocks leave at once.  A wave runs until the longest of its lanes'
-  // walks is over, issuing instructions for a handful of live lanes meanwhile;
-  // refilling only evens that out when a lane gets many rays, so the segment is
-  // served by no more blocks than give each lane w.rays_per_lane rays.
-  {
-    const uint32_t sibling = blockIdx.x / QUEUE_SEGMENTS; // 0 .. blocks per segment - 1
-    if (sibling > 0 && (size_t)sibling * blockDim.x * w.rays_per_lane >= n_in)
-      return;
-  }
 
   enum { EMPTY = 0, BUSY = 1, DRAIN = 2 }; // DRAIN: walk over, parked leaves left
   int state = EMPTY;
@@ -136,8 +127,6 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   int p0 = 0, p1 = 0, p2 = 0, p3 = 0, n_park = 0;
   uint32_t n_rays = 0;
   bool drained = false;
-  const unsigned long long dbg_t0 = wall_clock64();
-  unsigned dbg_iter = 0, dbg_refill = 0;
 
   // exact test of leaf `slot` for this lane's ray, folded into its nearest hit
   auto leaf = [&](int slot) -> bool {
@@ -148,9 +137,7 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
 
   while (true) {
     const int n_free = __builtin_popcountll(__ballot(state != BUSY));
-    dbg_iter++;
     if (n_free == 64 || (!drained && n_free >= w.fetch_at)) {
-      dbg_refill++;
       // ---- work off parked leaves, all lanes together ----
       while (__any(n_park > 0)) {
         if (n_park > 0) {
@@ -353,18 +340,6 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
     }
   }
   add_ray_count(w.ray_count, n_rays);
-  if (w.dbg) {
-    uint32_t tot = n_rays;
-    for (int off = 32; off > 0; off >>= 1)
-      tot += __shfl_down(tot, off, 64);
-    if (lane == 0) {
-      const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-      w.dbg[4 * wv + 0] = dbg_t0;
-      w.dbg[4 * wv + 1] = wall_clock64();
-      w.dbg[4 * wv + 2] = ((unsigned long long)dbg_refill << 32) | dbg_iter;
-      w.dbg[4 * wv + 3] = tot;
-    }
-  }
 }
 
 // k_shade — one ray of the level per lane: the triangles (renderer.cpp:156-166),
