@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--screen", choices=["auto", "off", "beam", "bvh"], default="auto",
                     help="work avoidance mode (rt_set_screen); off = plain every-ray-"
                          "every-sphere loop")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frames rendered concurrently, each on its own stream with its own "
+                         "resident scene copy (1 = strictly one frame at a time)")
     ap.add_argument("--lanes", type=int, default=None,
                     help="sub-frames in flight inside one rt_render_device call (rt_set_lanes)")
     args = ap.parse_args()
@@ -139,50 +142,61 @@ def main():
 
     band_rows = args.band_rows
     plan = BandPlan(h, w, band_rows, rank, world)
-    fb = plan.alloc_frame(dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    ds = rtamd.DeviceScene(sc)
     rtamd.set_screen(args.screen)
     if args.lanes is not None:
         rtamd.lib().rt_set_lanes(args.lanes)
-    send, recv = plan.alloc_gather(comm_dev)
-    # A second frame buffer lets the gather of frame k overlap the render of
-    # frame k+1 (the gather runs on the communicator's own stream).
-    n_buf = 2 if world > 1 else 1
-    fbs = [fb] + [plan.alloc_frame(dev) for _ in range(n_buf - 1)]
-    gath = [(send, recv)] + [plan.alloc_gather(comm_dev) for _ in range(n_buf - 1)]
-    events = []     # (start, end) pairs around the device work of each timed frame
-    pending = [None] * n_buf
+    # Frames in flight: a frame is a chain of ~16 dependent launches, each ending
+    # with a few long rays, so one frame alone cannot keep the chip busy once its
+    # share of the rays is small (N > 1).  Each slot has its own resident copy of
+    # the scene (its queues), its own stream and frame buffer; frame k+1 renders
+    # while frame k drains and while its bands travel to rank 0.
+    n_buf = max(1, args.frames_in_flight)
 
-    def finish(b):
-        """Frame in buffer b: wait for its gather and, on rank 0, put the other
-        ranks' bands in place.  The frame is then complete on GPU 0."""
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-            plan.scatter_received(fbs[b], gath[b][1])
+    class Slot:
+        pass
+    slots = []
+    for _ in range(n_buf):
+        sl = Slot()
+        sl.scene = rtamd.DeviceScene(sc)
+        sl.stream = torch.cuda.Stream(device=dev)
+        sl.fb = plan.alloc_frame(dev)
+        sl.send, sl.recv = plan.alloc_gather(comm_dev)
+        sl.pending = None
+        slots.append(sl)
+    ds = slots[0].scene
+    events = []     # (start, end) pairs around the device work of each timed frame
+
+    def finish(sl):
+        """Wait for the slot's gather and, on rank 0, put the other ranks' bands
+        in place.  The frame is then complete on GPU 0."""
+        if sl.pending is not None:
+            sl.pending.wait()
+            sl.pending = None
+            plan.scatter_received(sl.fb, sl.recv)
 
     def step(timed, k=0):
-        b = k % n_buf
-        finish(b)
-        if timed:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        ds.render_device(fbs[b].data_ptr(), None, w, h, max_depth=depth, band_rows=band_rows,
-                         band_index=rank, band_count=world, stream=stream,
-                         dev_ray_count=cnt.data_ptr())
-        if timed:
-            e1.record()
-            events.append((e0, e1))
-        pending[b] = plan.gather_to_rank0(fbs[b], gath[b][0], gath[b][1], async_op=True)
+        sl = slots[k % n_buf]
+        with torch.cuda.stream(sl.stream):
+            finish(sl)
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            sl.scene.render_device(sl.fb.data_ptr(), None, w, h, max_depth=depth,
+                                   band_rows=band_rows, band_index=rank, band_count=world,
+                                   stream=sl.stream.cuda_stream, dev_ray_count=cnt.data_ptr())
+            if timed:
+                e1.record()
+                events.append((e0, e1))
+            sl.pending = plan.gather_to_rank0(sl.fb, sl.send, sl.recv, async_op=True)
 
     def drain():
-        for b in range(n_buf):
-            finish(b)
+        for sl in slots:
+            with torch.cuda.stream(sl.stream):
+                finish(sl)
 
-    for k in range(args.warmup):
+    for k in range(max(args.warmup, n_buf)):
         step(False, k)
     drain()
     torch.cuda.synchronize()
@@ -199,7 +213,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    # device time of one frame's launches, first to last; with several frames in
+    # flight these intervals overlap, so this is a frame's latency, not 1/throughput
+    frame_latency_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+    kernel_ms = [dt / args.steps * 1e3] if n_buf > 1 else [e0.elapsed_time(e1) for e0, e1 in events]
 
     rays = cnt.clone()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -242,6 +259,8 @@ def main():
                                  "frac can exceed 1 (plain_loop = screen off)"},
         }
         out["config"]["screen"] = args.screen
+        out["config"]["frames_in_flight"] = n_buf
+        out["frame_latency_ms"] = frame_latency_ms
         if world == 1 and args.screen != "off" and sc.t_size + sc.s_size > PLAIN_LOOP_MAX_PRIMS:
             out["roofline"]["plain_loop"] = None   # minutes per frame at this size: not run
         elif world == 1 and args.screen != "off":
@@ -263,7 +282,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, w, h, depth)
         print(json.dumps(out))
-    ds.close()
+    for sl in slots:
+        sl.scene.close()
     if world > 1:
         dist.destroy_process_group()
 
