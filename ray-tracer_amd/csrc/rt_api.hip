@@ -523,18 +523,21 @@ static int render_lane(rt_scene *S, int lane, int n_lanes, const camera *cam, co
       wa.fetch_at = rt::WALK_FETCH_AT;
       wa.in = bd.in;
       wa.extra = S->extra.p;
-      // each ray is counted once, by the first walk it goes through
+      // Each ray is counted once, by the first walk it goes through.  The sphere
+      // walk goes first: it is several times cheaper per ray (a 320 KB tree in L2, 41
+      // instructions per child against ~90), and the |P| of its hit then bounds the
+      // triangle walk (a triangle only matters at |P| <= the sphere's, renderer.cpp:181).
+      wa.cursor = ctl(B, level, 1);
+      wa.hits = hl;
+      wa.ray_count = dev_ray_count;
+      HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
       if (tri_walks) {
         wa.cursor = ctl(B, level, 2);
         wa.hits = tl;
-        wa.ray_count = dev_ray_count;
+        wa.prior = hl;
+        wa.ray_count = nullptr;
         HIP_TRY(rt::launch_walk(sd, wa, false, true, kBounceBlocks, st));
-        wa.prior = tl;
       }
-      wa.cursor = ctl(B, level, 1);
-      wa.hits = hl;
-      wa.ray_count = tri_walks ? nullptr : dev_ray_count;
-      HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
       rt::ShadeArgs sa;
       memset(&sa, 0, sizeof sa);
       sa.rays = bd.in;
@@ -572,14 +575,18 @@ static int render_lane(rt_scene *S, int lane, int n_lanes, const camera *cam, co
           ws.fetch_at = rt::WALK_FETCH_AT;
           ws.in = sa.shadow;
           ws.extra = S->extra.p;
+          // spheres first (the cheaper walk); only what they leave unoccluded is
+          // worth a triangle walk
+          ws.cursor = ctl(B, level, 4 + 3 * g);
+          ws.ray_count = dev_ray_count;
+          ws.last_stage = tri_walks ? 0 : 1;
+          HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, ws_stream));
           if (tri_walks) {
             ws.cursor = ctl(B, level, 5 + 3 * g);
-            ws.ray_count = dev_ray_count;
+            ws.ray_count = nullptr;
+            ws.last_stage = 1;
             HIP_TRY(rt::launch_walk(sd, ws, true, true, kBounceBlocks, ws_stream));
           }
-          ws.cursor = ctl(B, level, 4 + 3 * g);
-          ws.ray_count = tri_walks ? nullptr : dev_ray_count;
-          HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, ws_stream));
           if (fork) {
             HIP_TRY(hipEventRecord(B->ev_join[par], B->side));
             joined[par] = true;

@@ -76,10 +76,11 @@ struct WalkArgs {
   RayQueue in;        // items to walk: (origin, tagA bits), (direction, tagB bits)
   uint32_t *cursor;   // cursor[s * CTL_WORDS]: next item of segment s to hand out
   HitList hits;       // nearest-hit walks: where hits go
-  HitList prior;      // sphere nearest-hit walks: the rays' triangle hits, or null
+  HitList prior;      // triangle nearest-hit walks: the rays' sphere hits (walked first), or null
   unsigned long long *extra; // shadow walks: tagA = pixel, tagB = packed integer
                              // light, added to the pixel if unoccluded
   uint64_t *ray_count;
+  int last_stage;     // shadow walks: 1 = add the light if unoccluded, 0 = cancel occluded items
   int fetch_at;       // refill a wave when this many of its lanes have nothing to do
 };
 

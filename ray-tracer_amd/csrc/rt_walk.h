@@ -95,9 +95,10 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
 //   ANY_HIT = false: item = bounce ray; the nearest hit of this class (P, |P|,
 //                    index or -1) is written to hits[slot of the ray]
 //   ANY_HIT = true : item = shadow ray (tagA = pixel, tagB = packed light).
-//                    Spheres: the light is added to the pixel if no sphere is hit.
-//                    Triangles: an occluded item is cancelled in place (direction
-//                    0, light 0) so that the sphere walk which follows drops it.
+//                    Last stage: the light is added to the pixel if nothing is hit.
+//                    Earlier stage (another class of primitive follows): an occluded
+//                    item is cancelled in place (direction 0, light 0), so that the
+//                    walk which follows finds nothing to do and nothing to add.
 // Leaves are single primitives.  Running the exact test the moment a leaf is
 // touched would make every iteration of the wave pay for it with one or two lanes
 // active, so a lane parks up to four touched leaves and the whole wave works
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
       // ---- hand in finished items ----
       if (state == DRAIN) {
         if (ANY_HIT) {
-          if (TRI) {
-            if (idx_s >= 0) // blocked by a triangle: cancel the item
+          if (!w.last_stage) {
+            if (idx_s >= 0) // blocked: cancel the item for the walk that follows
               w.in.items[2 * (seg_base + ray) + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
           } else if (idx_s < 0) { // unoccluded: renderer.cpp:119-127, as an integer sum
             add_light(w.extra, tagA, tagB);
@@ -219,8 +220,14 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
                       found |= leaf(slot);
                   if (!tr.usable || sc.n_tleaf == 0 || (ANY_HIT && found))
                     state = DRAIN;
-                  else if (!ANY_HIT)
+                  else if (!ANY_HIT) {
                     bound = len_s;
+                    // a triangle only matters if it is at least as near as the ray's
+                    // nearest sphere (renderer.cpp:181; the prune comparison is strict,
+                    // so a tie survives)
+                    if (w.prior.idx != nullptr && w.prior.idx[seg_base + r] >= 0)
+                      bound = fminf(bound, w.prior.rec[seg_base + r].w);
+                  }
                 }
               } else {
                 a = dot3(dx, dy, dz, dx, dy, dz); // maths.cpp:127
@@ -230,10 +237,6 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
                 iy = wr.iy;
                 iz = wr.iz;
                 da = wr.ida;
-                // a sphere only matters if it is strictly nearer than the ray's
-                // nearest triangle (renderer.cpp:181)
-                if (!ANY_HIT && w.prior.idx != nullptr && w.prior.idx[seg_base + r] >= 0)
-                  bound = w.prior.rec[seg_base + r].w;
                 // (Bounding the walk by the looped triangles' nearest hit as well was
                 // measured: the tests run on the few lanes that are refilling and cost
                 // more than the pruning saves, 9.27 ms against 8.76 ms per frame.)
