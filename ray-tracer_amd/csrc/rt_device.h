@@ -536,6 +536,7 @@ template <bool ANY_HIT, bool VERIFY = false>
 __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, float oy, float oz,
                                                float dx, float dy, float dz, float &len_t,
                                                int &idx_t, float &tPx, float &tPy, float &tPz,
+                                               float outer_bound = RT_INF,
                                                unsigned long long *counters = nullptr) {
   const TriWalkRay r = tri_walk_ray(ox, oy, oz, dx, dy, dz);
   if (!r.possible)
@@ -556,7 +557,8 @@ __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, flo
   }
   int stack[BVH_STACK];
   int sp = 0, node = 0;
-  float bound = ANY_HIT ? RT_INF : len_t;
+  // outer_bound: a |P| beyond which a triangle hit cannot matter to the caller
+  float bound = ANY_HIT ? RT_INF : fminf(len_t, outer_bound);
   unsigned n_bounds = 0, n_leaf = 0;
   while (true) {
     const TriNode N = sc.tbvh[node];
@@ -617,12 +619,11 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
 
   // ---- triangles, renderer.cpp:156-166 ----
-  // (the plain-loop build carries no walk code: it is the brute-force yardstick)
-  if (BEAM != RT_BEAM_NONE && sc.tbvh != nullptr) {
-    if (live)
-      walk_triangles<ANY_HIT, VERIFY>(sc, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz,
-                                      st.twalk);
-  } else {
+  // With a triangle hierarchy the triangles are walked AFTER the spheres (below):
+  // the sphere walk is several times cheaper and its hit bounds the triangle walk.
+  // (The plain-loop build carries no walk code: it is the brute-force yardstick.)
+  const bool tri_walk = BEAM != RT_BEAM_NONE && sc.tbvh != nullptr;
+  if (!tri_walk) {
     for (int i = 0; i < sc.t_size; i++) {
       const TriRec &T = sc.tri[i];
       float no = FROM_EYE ? T.p1_no.w
@@ -845,6 +846,13 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
           break;
       }
     }
+  }
+
+  if (tri_walk && live && !(ANY_HIT && idx_s >= 0)) {
+    // a triangle only matters at |P| <= the nearest sphere's (renderer.cpp:181);
+    // the walk's prune comparison is strict, so a tie survives
+    walk_triangles<ANY_HIT, VERIFY>(sc, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz,
+                                    len_s, st.twalk);
   }
 
   // ---- renderer.cpp:179-192 ----
