@@ -218,6 +218,9 @@ def main():
     frame_latency_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
     kernel_ms = [dt / args.steps * 1e3] if n_buf > 1 else [e0.elapsed_time(e1) for e0, e1 in events]
 
+    for sl in slots:
+        if sl.scene.queue_overflowed():
+            raise SystemExit("bounce-ray queue overflowed: the frames are incomplete, no number reported")
     rays = cnt.clone()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
