@@ -335,3 +335,38 @@ def test_wild_scene_frames_in_every_mode(oracle):
             rtamd.set_screen("auto")
         assert_frame_parity(fb, ids, fo, io, f"wild scene, mode {mode}")
         assert n == no
+
+
+def test_axis_parallel_rays_on_box_faces(oracle):
+    """The sphere hierarchy bounds its children by boxes and tests them with slabs
+    (1 / direction per axis).  On the reference's grid every box face sits on an
+    integer coordinate, so rays from lattice points along the axes and the face
+    diagonals hit every special case of that arithmetic at once: zero direction
+    components (infinite reciprocals), origins exactly on face planes (0 x inf),
+    rays running inside a face, rays starting on a sphere's surface and centre.
+    Every mode must give the loop's answer."""
+    sc = rtamd.grid_scene(20, 20)
+    dirs = []
+    for d in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, -1, 0),
+              (1, 1, 1), (2, 0, 0), (0, 0, 0.25), (1e-30, 0, 1), (0, 1e-38, -1), (-0.0, 1, 0)):
+        dirs += [d, tuple(-x for x in d)]
+    origins = []
+    for x in (-21, -20, -19, -1, 0, 1, 20):
+        for y in (-21, -20, -10, -9, 0, 1):
+            for z in (-52, -51, -50, -49, -48, 1):
+                origins.append((x, y, z))
+    o = np.repeat(np.array(origins, np.float32), len(dirs), axis=0)
+    d = np.tile(np.array(dirs, np.float32), (len(origins), 1))
+    k0, i0, p0 = oracle.check_intersection(sc, o, d)
+    assert (k0 == 2).mean() > 0.2
+    for mode in ("off", "bvh", "auto"):
+        try:
+            rtamd.set_screen(mode)
+            with rtamd.DeviceScene(sc) as ds:
+                k1, i1, p1 = ds.check_intersection(o, d)
+        finally:
+            rtamd.set_screen("auto")
+        assert np.array_equal(k0, k1), (mode, int((k0 != k1).sum()))
+        hit = k0 != 0
+        assert np.array_equal(i0[hit], i1[hit]), mode
+        assert np.array_equal(p0.view(np.uint32)[hit], p1.view(np.uint32)[hit]), mode
