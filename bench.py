@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--screen", choices=["auto", "off", "beam", "bvh"], default="auto",
                     help="work avoidance mode (rt_set_screen); off = plain every-ray-"
                          "every-sphere loop")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames rendered concurrently, each on its own stream with its own "
                          "resident scene copy (1 = strictly one frame at a time)")
     ap.add_argument("--lanes", type=int, default=None,
@@ -152,6 +152,9 @@ def main():
     # the scene (its queues), its own stream and frame buffer; frame k+1 renders
     # while frame k drains and while its bands travel to rank 0.
     n_buf = max(1, args.frames_in_flight)
+    # several frames in flight: one stream per frame, no side streams inside a
+    # frame (the device has 4 hardware queues; streams sharing one serialise)
+    rtamd.lib().rt_set_side_stream(1 if n_buf == 1 else 0)
 
     class Slot:
         pass

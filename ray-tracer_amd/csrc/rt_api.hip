@@ -68,6 +68,7 @@ template <typename T> struct DevBuf {
 // with 1 lane, 8.80 with 2, 9.92 with 3, 9.69 with 4; 1 is the default.
 constexpr int kMaxLanes = 4;
 int g_lanes = 1;
+int g_side_stream = 1; // rt_set_side_stream
 
 struct BounceLane {
   DevBuf<float4> queue[2];
@@ -550,7 +551,7 @@ static int render_lane(rt_scene *S, int lane, int n_lanes, const camera *cam, co
       const int per_ray = S->l_size < kLightGroup ? (S->l_size > 0 ? S->l_size : 1) : kLightGroup;
       // one group of lights: its shadow walks go to the side stream; more groups
       // share the item buffer and stay in order on the caller's stream
-      const bool fork = n_groups == 1 && S->l_size > 0;
+      const bool fork = n_groups == 1 && S->l_size > 0 && g_side_stream != 0;
       const int par = level & 1;
       for (int g = 0; g < n_groups; g++) {
         sa.light_begin = g * kLightGroup;
@@ -684,6 +685,8 @@ int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {
   return RT_OK;
 }
 
+void rt_set_side_stream(int on) { g_side_stream = on != 0; }
+int rt_get_side_stream(void) { return g_side_stream; }
 void rt_set_lanes(int n) { g_lanes = n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n); }
 int rt_get_lanes(void) { return g_lanes; }
 void rt_set_screen(int enabled) { g_screen = enabled; }

@@ -165,6 +165,8 @@ def lib() -> C.CDLL:
     L.rt_set_screen.restype = None
     L.rt_set_lanes.argtypes = [C.c_int]
     L.rt_set_lanes.restype = None
+    L.rt_set_side_stream.argtypes = [C.c_int]
+    L.rt_set_side_stream.restype = None
     L.gpu_check_intersection.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L

@@ -122,7 +122,8 @@ def test_screen_off_gives_the_same_bounces(oracle):
 
 def test_lane_count_does_not_change_the_frame(oracle):
     """rt_set_lanes splits a bounce frame into sub-frames of alternate row bands
-    on separate streams; pixels, ids and ray counts must not depend on it."""
+    on separate streams, rt_set_side_stream moves the shadow walks to a stream of
+    their own; pixels, ids and ray counts must not depend on either."""
     sc = material_scene(55, n_spheres=150, n_tris=6, n_lights=2)
     fo, io, no = oracle.render(sc, 384, 216, max_depth=6)
     try:
@@ -133,8 +134,14 @@ def test_lane_count_does_not_change_the_frame(oracle):
             assert np.array_equal(ids, io), lanes
             assert np.array_equal(fb, fo), lanes
             assert n == no, lanes
+        rtamd.lib().rt_set_lanes(1)
+        for side in (0, 1):
+            rtamd.lib().rt_set_side_stream(side)
+            fb, ids, n = rtamd.render(sc, 384, 216, max_depth=6)
+            assert np.array_equal(ids, io) and np.array_equal(fb, fo) and n == no, side
     finally:
         rtamd.lib().rt_set_lanes(1)
+        rtamd.lib().rt_set_side_stream(1)
 
 
 def test_invalid_materials_rejected():
