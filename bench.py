@@ -97,8 +97,8 @@ def cpu_baseline(sc, w, h, depth, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
