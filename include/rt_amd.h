@@ -146,12 +146,17 @@ int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
  *     shadow rays: the light) are bounded by a cone, the spheres are screened
  *     64 at a time (one per lane) against that cone, and the reference's per-ray
  *     arithmetic runs only on spheres the cone can touch;
- *   - sphere hierarchy: a bounding-sphere tree built at rt_scene_create; each
+ *   - sphere hierarchy: a tree of boxes built at rt_scene_create; each
  *     lane walks it for its own ray (bounce rays, bulk queries, and by default
- *     also primary and shadow rays).
- * Both are conservative by construction, so images, ids and ray counts are
+ *     also primary and shadow rays);
+ *   - triangle hierarchy: scenes with 16 or more triangles get a tree over the
+ *     triangles as well, with bounds that follow the reference's own triangle
+ *     arithmetic (maths.cpp:77-78: the test is the textbook one seen from the ray
+ *     origin mirrored in the plane through the world origin with the triangle's
+ *     normal).
+ * All are conservative by construction, so images, ids and ray counts are
  * identical in every mode.  mode: 0 = plain loop, every ray against every
- * sphere (used to measure the brute-force roofline); 1 = automatic (default);
+ * primitive (used to measure the brute-force roofline); 1 = automatic (default);
  * 2 = beam screen for primary/shadow rays; 3 = hierarchy for all rays.
  * Process-wide; not thread-safe against concurrent renders.                   */
 void rt_set_screen(int mode);

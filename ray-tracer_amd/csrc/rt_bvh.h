@@ -1,4 +1,4 @@
-// rt_bvh.h — bounding-sphere hierarchy over the scene's spheres.
+// rt_bvh.h — hierarchy of boxes over the scene's spheres.
 //
 // Used for rays that do not travel in coherent bundles (bounce rays, bulk
 // check_intersection queries): each lane walks the tree for its own ray with a

@@ -47,7 +47,7 @@ struct SceneDev {
   const float4 *mat_sph;
   const float4 *lights;  // xyz
   int t_size, s_size, s_pad, l_size;
-  // bounding-sphere hierarchy over the spheres (rt_bvh.h); bvh == nullptr: none
+  // hierarchy of boxes over the spheres (rt_bvh.h); bvh == nullptr: none
   const BvhNode *bvh;
   const float4 *leaf_geo;    // sph_geo gathered into leaf order
   const int32_t *leaf_idx;   // original sphere index of each leaf slot
@@ -323,7 +323,7 @@ __device__ __forceinline__ bool beam_keeps(const Beam &B, float4 g) {
 //           wave's rays share the apex (Xx,Xy,Xz) (the eye, or the light a shadow
 //           ray aims at) and are screened as a bundle; Dk is the lane's distance
 //           from its ray origin to the apex.  RT_ACCEL_BVH = no bundle: each lane
-//           walks the bounding-sphere hierarchy for its own ray (bvh_touches).
+//           walks the sphere hierarchy for its own ray (bvh_touches).
 //
 // Nearest is by |P| from the WORLD origin with strict '>' (lowest index wins in
 // a class); between classes a triangle wins ties ('<=', renderer.cpp:181).  A
