@@ -139,6 +139,15 @@ int rt_render_device(rt_scene *scene, const camera *cam, const rt_frame *frame,
  * gpu_render/gpu_render_ids check it themselves and return RT_ERR_CAPACITY).  */
 int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
 
+/* Capacity of the bounce-ray queues of later rt_render_device calls: n rays per
+ * owned pixel and bounce level (1..256, default 4; + 65536).  256 can never
+ * overflow: every queued ray carries a weight of at least 2^-8 and the weights
+ * of a pixel's rays at one level sum to at most 1.  A caller that finds
+ * rt_scene_queue_overflowed set raises it and renders the frame again;
+ * gpu_render / gpu_render_ids do exactly that by themselves (x8 per attempt).
+ * No counterpart in the reference.                                            */
+int rt_scene_set_rays_per_pixel(rt_scene *scene, int n);
+
 /* ---- work avoidance (no counterpart in the reference) ----------------------
  * The reference tests every ray against every primitive (renderer.cpp:156-177).
  * The library gets the same answers with far fewer tests, in two ways:

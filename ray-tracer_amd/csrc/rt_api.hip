@@ -122,6 +122,10 @@ struct rt_scene {
   float eye[3] = {0, 0, 0};
   // bounce machinery, allocated on the first max_depth > 1 render
   BounceLane lanes[kMaxLanes];
+  // queue capacity per level: this many rays per owned pixel (+ 65536).  No level
+  // can hold more than 256 per pixel: every queued ray weighs >= 2^-8 and the
+  // weights of one pixel's rays at one level sum to at most 1.
+  int rays_per_pixel = 4;
   DevBuf<unsigned long long> extra; // per pixel, 3 x 21 bits
   size_t extra_pixels = 0;
   hipEvent_t ev_begin = nullptr;
@@ -332,7 +336,7 @@ constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
 
 int ensure_bounce_buffers(rt_scene *S, BounceLane *B, bool own_stream, size_t frame_pixels,
                           size_t owned_pixels) {
-  size_t want = 4 * owned_pixels + 65536;
+  size_t want = (size_t)S->rays_per_pixel * owned_pixels + 65536;
   if (want > 0x0ffffff0ull)
     want = 0x0ffffff0ull;
   want = (want + rt::QUEUE_SEGMENTS - 1) / rt::QUEUE_SEGMENTS * rt::QUEUE_SEGMENTS;
@@ -685,6 +689,15 @@ int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {
   return RT_OK;
 }
 
+int rt_scene_set_rays_per_pixel(rt_scene *S, int n) {
+  if (!S)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  if (n < 1 || n > 256)
+    return fail(RT_ERR_BAD_ARG, "rays per pixel %d outside 1..256", n);
+  S->rays_per_pixel = n;
+  return RT_OK;
+}
+
 void rt_set_side_stream(int on) { g_side_stream = on != 0; }
 int rt_get_side_stream(void) { return g_side_stream; }
 void rt_set_lanes(int n) { g_lanes = n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n); }
@@ -724,19 +737,28 @@ int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
     fr.band_index = 0;
     fr.band_count = 1;
     fr.stream = nullptr;
-    int r = rt_render_device(S, cam, &fr, cnt.p);
-    if (r)
-      return r;
+    // render; if a bounce queue overflowed, again with eight times the capacity
+    // (at 256 rays per pixel it cannot overflow)
+    for (;;) {
+      HIP_TRY(hipMemset(cnt.p, 0, sizeof(uint64_t)));
+      int r = rt_render_device(S, cam, &fr, cnt.p);
+      if (r)
+        return r;
+      HIP_TRY(hipStreamSynchronize(nullptr));
+      int over = 0;
+      if ((r = rt_scene_queue_overflowed(S, &over)))
+        return r;
+      if (!over)
+        break;
+      if (S->rays_per_pixel >= 256)
+        return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
+      S->rays_per_pixel = S->rays_per_pixel * 8 > 256 ? 256 : S->rays_per_pixel * 8;
+    }
     HIP_TRY(hipMemcpy(rgb, fb.p, npx * 4, hipMemcpyDeviceToHost));
     if (hit_ids)
       HIP_TRY(hipMemcpy(hit_ids, ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (n_rays)
       HIP_TRY(hipMemcpy(n_rays, cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    int over = 0;
-    if ((r = rt_scene_queue_overflowed(S, &over)))
-      return r;
-    if (over)
-      return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
     return RT_OK;
   };
   rc = body();

@@ -254,6 +254,10 @@ class DeviceScene:
             _check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(f),
                                           dev_ray_count))
 
+    def set_rays_per_pixel(self, n: int):
+        """rt_scene_set_rays_per_pixel: bounce-queue capacity of later frames."""
+        _check(lib().rt_scene_set_rays_per_pixel(self.handle, n))
+
     def queue_overflowed(self) -> bool:
         """rt_scene_queue_overflowed: did the last frame drop bounce rays?"""
         flag = C.c_int(0)

@@ -144,6 +144,36 @@ def test_lane_count_does_not_change_the_frame(oracle):
         rtamd.lib().rt_set_side_stream(1)
 
 
+def test_queue_capacity_grows_when_rays_multiply(oracle):
+    """Half mirror, half transparent everywhere: every hit doubles the rays, up
+    to 256 per pixel at depth 9 (the weight cut-off 2^-8), far beyond the default
+    queue of 4 per pixel.  rt_render_device flags the overflow; with a larger queue
+    (rt_scene_set_rays_per_pixel) the frame is complete; gpu_render_ids grows the
+    queue by itself.  Complete frames equal the oracle's."""
+    import torch
+    sc = golden_scenes.mixed_scene(seed=77, n_spheres=80, n_tris=6, n_lights=1)
+    sc.mat_sphere = np.tile(np.array([0.5, 0.5, 1.0, 0], np.float32), (sc.s_size, 1))
+    sc.mat_tri = np.tile(np.array([0.5, 0.5, 1.0, 0], np.float32), (sc.t_size, 1))
+    w, h, depth = 256, 144, 9
+    fo, io, no = oracle.render(sc, w, h, max_depth=depth)
+    assert no > 30 * w * h          # the rays really multiply
+    fb, ids, n = rtamd.render(sc, w, h, max_depth=depth)
+    assert np.array_equal(ids, io) and np.array_equal(fb, fo) and n == no
+    dev = torch.device("cuda", 0)
+    out = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    with rtamd.DeviceScene(sc) as ds:
+        ds.render_device(out.data_ptr(), None, w, h, max_depth=depth)
+        torch.cuda.synchronize()
+        assert ds.queue_overflowed()
+        ds.set_rays_per_pixel(256)
+        ds.render_device(out.data_ptr(), None, w, h, max_depth=depth)
+        torch.cuda.synchronize()
+        assert not ds.queue_overflowed()
+        assert np.array_equal(out.cpu().numpy(), fo)
+        with pytest.raises(rtamd.RtError):
+            ds.set_rays_per_pixel(257)
+
+
 def test_invalid_materials_rejected():
     sc = golden_scenes.mixed_scene()
     sc.mat_sphere = np.zeros((sc.s_size, 4), np.float32)

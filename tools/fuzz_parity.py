@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign: for each seed a random scene (sphere cloud with
 radii over three decades, triangle soup of 0..300 triangles so that both the
-looped and the hierarchy path occur, random materials, 1..5 lights, a random
+looped and the hierarchy path occur, random materials, 1..17 lights, a random
 camera), one frame at a random depth through the C ABI against the CPU oracle
 (ids, bytes, ray count), and a batch of random rays through check_intersection.
 usage: fuzz_parity.py [first_seed] [n_seeds]"""
@@ -38,7 +38,7 @@ def scene(seed):
     tcol = rng.randint(0, 256, (nt, 3)).astype(np.uint8)
     if rng.rand() < 0.5:
         tri = np.concatenate([rtamd.WALL_TRIS, tri]); tcol = np.concatenate([rtamd.WALL_COLOR, tcol])
-    nl = int(rng.randint(1, 6))
+    nl = int(rng.choice([1, 1, 2, 3, 5, 9, 17]))   # up to five groups of four lights
     lights = np.stack([rng.uniform(-20, 20, nl), rng.uniform(-10, 20, nl), rng.uniform(-30, 10, nl)], -1).astype(np.float32)
     sc = rtamd.Scene(tri, tcol, c, r, col, lights)
     if rng.rand() < 0.8:
