@@ -66,6 +66,8 @@ def main():
     for seed in range(first, first + count):
         sc, cam, rng = scene(seed)
         w, h = int(rng.choice([64, 100, 192])), int(rng.choice([40, 72, 108]))
+        if os.environ.get("FUZZ_BIG"):   # frames large enough for every block of the persistent grids
+            w, h = 8 * w, 8 * h
         depth = int(rng.choice([1, 2, 4, 9]))
         fb, ids, n = rtamd.render(sc, w, h, max_depth=depth, cam=cam)
         fo, io, no = o.render(sc, w, h, max_depth=depth, cam=cam)
