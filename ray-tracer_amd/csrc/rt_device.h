@@ -432,6 +432,9 @@ __device__ __forceinline__ SphWalkRay sph_walk_ray(float dx, float dy, float dz,
 // hit, t~ |d|^2 <= (C - q).d + Rtot |d| (so a child entirely behind q cannot be
 // hit: maths.cpp:80 rejects t < 0), and |P~| >= |C + (o - q)| - Rtot.  NaN or inf
 // anywhere answers yes.  `ol` >= |o|, `da` >= |d|.
+// NEAREST false (any-hit walks: no best |P| to prune against, no visiting order to
+// choose): the last exit is not evaluated and near_out is 0.
+template <bool NEAREST = true>
 __device__ __forceinline__ bool tri_touches(float4 s, uint2 ns, float ox, float oy, float oz,
                                             float dx, float dy, float dz, float a, float da,
                                             float ol, float bound, float &near_out) {
@@ -464,10 +467,14 @@ __device__ __forceinline__ bool tri_touches(float4 s, uint2 ns, float ox, float 
   const float lhs = fmaf(-md, md, (a * m2) * 0.99999809265136719f);
   const float rhs = (a * Rtot) * (Rtot * 1.000001f);
   const bool behind = fmaf(da, Rtot * 1.0001f, md) < 0.f;
-  const float fx = Mx + ox, fy = My + oy, fz = Mz + oz; // C + (o - q)
-  const float flen = __builtin_amdgcn_sqrtf(fmaf(fz, fz, fmaf(fy, fy, fx * fx)));
-  near_out = fmaf(flen, 0.999998f, -(Rtot * 1.000002f));
-  const bool far = near_out > bound;
+  bool far = false;
+  near_out = 0.f;
+  if (NEAREST) {
+    const float fx = Mx + ox, fy = My + oy, fz = Mz + oz; // C + (o - q)
+    const float flen = __builtin_amdgcn_sqrtf(fmaf(fz, fz, fmaf(fy, fy, fx * fx)));
+    near_out = fmaf(flen, 0.999998f, -(Rtot * 1.000002f));
+    far = near_out > bound;
+  }
   return !(lhs > rhs) && !behind && !far;
 }
 
@@ -570,7 +577,8 @@ __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, flo
       const int32_t link = N.link[c];
       float near;
       if (link == BVH_EMPTY ||
-          !tri_touches(N.s[c], N.ns[c], ox, oy, oz, dx, dy, dz, r.a, r.da, r.ol, bound, near))
+          !tri_touches<!ANY_HIT>(N.s[c], N.ns[c], ox, oy, oz, dx, dy, dz, r.a, r.da, r.ol, bound,
+                                 near))
         continue;
       if (link >= 0) {
         int push = link;

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
           links[c] = N.link[c];
           nears[c] = RT_INF;
           touch[c] = links[c] != BVH_EMPTY &&
-                     tri_touches(N.s[c], N.ns[c], ox, oy, oz, dx, dy, dz, a, da, ol, bound,
-                                 nears[c]);
+                     tri_touches<!ANY_HIT>(N.s[c], N.ns[c], ox, oy, oz, dx, dy, dz, a, da, ol,
+                                           bound, nears[c]);
         }
       } else {
         const BvhNode N = sc.bvh[node];
