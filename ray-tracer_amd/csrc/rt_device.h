@@ -374,9 +374,12 @@ struct ScreenStats { // filled only by the verification build of the kernels
 //    discriminant carries an absolute error <= 17u (2|d||L|)^2, i.e. <= 1e-3 |L|
 //    on the roots), so such a child cannot supply a nearer hit.  Ties are kept:
 //    the comparison is strict.
+// entry_out: the parameter at which the line enters the grown box (an ordering key
+// for any-hit walks: the nearer an occluder is to the ray's origin, the sooner it
+// ends the walk).
 __device__ __forceinline__ bool bvh_touches(float4 a, float4 b, float ox, float oy, float oz,
                                             float ix, float iy, float iz, float ida,
-                                            float bound) {
+                                            float bound, float &entry_out) {
   const float ax = a.x - ox, ay = a.y - oy, az = a.z - oz;
   const float bx = a.w - ox, by = b.x - oy, bz = b.y - oz;
   const float S1 = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) +
@@ -391,6 +394,7 @@ __device__ __forceinline__ bool bvh_touches(float4 a, float4 b, float ox, float 
   const float mu = S1 * 0.0045f;
   const bool behind = tmax < -(mu * ida);
   const bool far = (b.z - mu) > bound;
+  entry_out = tmin;
   return !miss && !behind && !far;
 }
 
@@ -746,17 +750,19 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
 #pragma unroll
           for (int c = 0; c < BVH_WIDTH; c++) {
             const int32_t link = __float_as_int(N.b[c].w);
-            if (link == BVH_EMPTY ||
-                !bvh_touches(N.a[c], N.b[c], ox, oy, oz, wr.ix, wr.iy, wr.iz, wr.ida, bound))
+            float entry;
+            if (link == BVH_EMPTY || !bvh_touches(N.a[c], N.b[c], ox, oy, oz, wr.ix, wr.iy, wr.iz,
+                                                  wr.ida, bound, entry))
               continue;
             if (link >= 0) {
               // keep the child nearest to the world origin for the next visit (it
               // tightens `bound`), stack the others
+              const float key = N.b[c].z;
               int push = link;
-              if (N.b[c].z < next_near) {
+              if (key < next_near) {
                 push = next;
                 next = link;
-                next_near = N.b[c].z;
+                next_near = key;
               }
               if (push >= 0 && sp < BVH_STACK)
                 stack[sp++] = push;
