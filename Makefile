@@ -11,7 +11,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 CSRC     := ray-tracer_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC \
-            -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function
+            -fno-fast-math -Wall -Wno-unused-function
 LIB      := $(CSRC)/librt_amd.so
 SRCS     := $(CSRC)/rt_kernels.hip $(CSRC)/rt_api.hip $(CSRC)/rt_bvh.cpp $(CSRC)/rt_tribvh.cpp
 HDRS     := $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/rt_bvh.h $(CSRC)/rt_tribvh.h $(CSRC)/rt_walk.h include/rt_amd.h

@@ -83,9 +83,6 @@ struct Builder {
                      });
   }
 
-  // Child k of node N: the box as centre and half-extent (what the slab test
-  // multiplies with), both floats, the half-extent rounded up so that
-  // [centre - half, centre + half] contains B.
   static void store(BvhNode &N, int k, const Box &B, int32_t link, bool present) {
     union {
       int32_t i;
@@ -93,17 +90,8 @@ struct Builder {
     } bits;
     bits.i = link;
     if (present) {
-      float c[3], h[3];
-      Box G;
-      for (int d = 0; d < 3; d++) {
-        c[d] = (float)(0.5 * ((double)B.lo[d] + (double)B.hi[d]));
-        const double need = std::max((double)B.hi[d] - (double)c[d], (double)c[d] - (double)B.lo[d]);
-        h[d] = round_up(need);
-        G.lo[d] = round_down((double)c[d] - (double)h[d]);
-        G.hi[d] = round_up((double)c[d] + (double)h[d]);
-      }
-      N.a[k] = make_float4(c[0], c[1], c[2], h[0]);
-      N.b[k] = make_float4(h[1], h[2], near_bound(G), bits.f);
+      N.a[k] = make_float4(B.lo[0], B.lo[1], B.lo[2], B.hi[0]);
+      N.b[k] = make_float4(B.hi[1], B.hi[2], near_bound(B), bits.f);
     } else {
       N.a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       N.b[k] = make_float4(0.f, 0.f, INFINITY, bits.f);

@@ -23,10 +23,10 @@ namespace rt {
 // leaf, ~link = (slot << 3) into the leaf arrays (one sphere per leaf).
 constexpr int BVH_WIDTH = 4;
 struct alignas(128) BvhNode {
-  // child c: a[c] = (centre.xyz, half.x), b[c] = (half.y, half.z, near, bits of link).
-  // The box centre +- half covers every member sphere entirely; near = distance
-  // from the world origin to the box, rounded down (no point of the child is
-  // closer than this); link = BVH_EMPTY: no such child.
+  // child c: a[c] = (lo.x, lo.y, lo.z, hi.x), b[c] = (hi.y, hi.z, near, bits of link).
+  // [lo, hi] covers every member sphere entirely; near = distance from the world
+  // origin to the box, rounded down (no point of the child is closer than this);
+  // link = BVH_EMPTY: no such child.
   float4 a[BVH_WIDTH];
   float4 b[BVH_WIDTH];
 };

@@ -346,22 +346,21 @@ struct ScreenStats { // filled only by the verification build of the kernels
 #define RT_BEAM_APEX 1
 #define RT_ACCEL_BVH 3
 
-// Can the line {o + t d} touch any sphere inside the box of a child (a = centre.xyz,
-// half.x; b = half.yz, near, link)?  Must say yes whenever the float discriminant
-// test (maths.cpp:132-133) can pass for a member sphere (centre c, radius r,
-// entirely inside the box).  From the bound above,
+// Can the line {o + t d} touch any sphere inside the box [lo, hi] of a child
+// (a = lo.xyz, hi.x; b = hi.yz, near, link)?  Must say yes whenever the float
+// discriminant test (maths.cpp:132-133) can pass for a member sphere (centre c,
+// radius r, entirely inside the box).  From the bound above,
 //   dist(c, line) <= r sqrt(1+64u) + sqrt(64u) |o - c|,  sqrt(64u) = 2^-9,
-// and |o - c| <= S1 := sum over the axes of |centre - o| + half, r <= S1 / 3, so
-// the line passes within 0.002 S1 of the box, i.e. through the box grown by
+// and |o - c| <= S1 := sum over the axes of max(|lo - o|, |hi - o|), r <= S1 / 3,
+// so the line passes within 0.002 S1 of the box, i.e. through the box grown by
 // m = 0.0021 S1 on every side (the extra 1e-4 S1 is thousands of times the
-// rounding of the slab arithmetic below).  Per axis the line is inside the slab
-// for parameters tc - th .. tc + th with tc = (centre - o) / d, th = (half + m) / |d|;
-// the child is kept unless the largest entry exceeds the smallest exit by more
-// than 2^-20 of their magnitudes (each carries <= 4u relative error).  ix, iy,
-// iz = 1/d per axis: a zero component gives th = inf and tc = +-inf or NaN, the
-// slab then constrains nothing (minimum and maximum skip NaN) - exact when o
-// lies inside it, merely not used for culling when o lies outside; NaN elsewhere
-// answers yes.
+// rounding of the slab arithmetic below).  The slab test keeps the child unless
+// the entry parameter exceeds the exit parameter by more than 2^-20 of their
+// magnitudes (each carries <= 4u relative error).  ix, iy, iz = 1/d per axis:
+// a zero component gives +-inf, the slab then constrains nothing when o lies
+// inside it and rejects when o lies outside; NaN (0 x inf, inf - inf) answers
+// yes, except for a line exactly in a face plane of the grown box, which cannot
+// belong to a candidate (the true margin is strictly smaller).
 //
 // Two more ways out, both one-sided, with mu = 0.0045 S1 > 2^-8 (|o - c| + r):
 //  - the grown box lies behind the ray origin by more than mu: its exit
@@ -381,13 +380,16 @@ struct ScreenStats { // filled only by the verification build of the kernels
 __device__ __forceinline__ bool bvh_touches(float4 a, float4 b, float ox, float oy, float oz,
                                             float ix, float iy, float iz, float ida,
                                             float bound, float &entry_out) {
-  const float Mx = a.x - ox, My = a.y - oy, Mz = a.z - oz;
-  const float S1 = ((fabsf(Mx) + a.w) + (fabsf(My) + b.x)) + (fabsf(Mz) + b.y);
+  const float ax = a.x - ox, ay = a.y - oy, az = a.z - oz;
+  const float bx = a.w - ox, by = b.x - oy, bz = b.y - oz;
+  const float S1 = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) +
+                   fmaxf(fabsf(az), fabsf(bz));
   const float m = S1 * 0.0021f;
-  const float tcx = Mx * ix, tcy = My * iy, tcz = Mz * iz;
-  const float thx = (a.w + m) * fabsf(ix), thy = (b.x + m) * fabsf(iy), thz = (b.y + m) * fabsf(iz);
-  const float tmin = fmaxf(fmaxf(tcx - thx, tcy - thy), tcz - thz);
-  const float tmax = fminf(fminf(tcx + thx, tcy + thy), tcz + thz);
+  const float t0x = (ax - m) * ix, t1x = (bx + m) * ix;
+  const float t0y = (ay - m) * iy, t1y = (by + m) * iy;
+  const float t0z = (az - m) * iz, t1z = (bz + m) * iz;
+  const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+  const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
   const bool miss = (tmin - tmax) > 9.5367431640625e-07f * (fabsf(tmin) + fabsf(tmax));
   const float mu = S1 * 0.0045f;
   const bool behind = tmax < -(mu * ida);
