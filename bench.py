@@ -24,6 +24,7 @@ import rtamd  # noqa: E402
 from rt_shard import BandPlan  # noqa: E402
 
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32, FMA counted as 2 flop
+PEAK_HBM_GBS = 8000.0           # MI355X HBM3E
 FLOP_PER_SPHERE_TEST = 25       # maths.cpp:126-133 up to the discriminant test
 FLOP_PER_TRIANGLE_TEST = 107    # maths.cpp:68-116 full path
 
@@ -264,6 +265,13 @@ def main():
                                  "of that arithmetic is proven unnecessary and skipped, so "
                                  "frac can exceed 1 (plain_loop = screen off)"},
         }
+        # the same launches against the HBM roofline (not the bound of this path:
+        # the scene sits in L2; reported so that both rooflines can be read off)
+        traffic = out["roofline"]["traffic"]
+        if traffic:
+            gbs = traffic / (k_ms * 1e-3) / 1e9
+            out["roofline"]["hbm"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": gbs / PEAK_HBM_GBS}
         out["config"]["screen"] = args.screen
         out["config"]["frames_in_flight"] = n_buf
         out["frame_latency_ms"] = frame_latency_ms
