@@ -64,3 +64,34 @@ def test_two_ranks_rebuild_the_single_gpu_frame(tmp_path, depth):
                                want_ids=False)
     assert np.array_equal(np.load(out), whole)
     assert int(np.load(out + ".rays.npy")[0]) == n
+
+
+def test_eight_way_split_of_the_4k_depth8_frame():
+    """The multi-GPU configuration's work split, on one GPU: the 10 000-sphere
+    3840x2160 depth-8 frame rendered as the eight ranks of an 8-way run would
+    (bands of 8 rows, band b to rank b mod 8), one rank after the other into one
+    buffer.  The result must be the whole-frame render, byte for byte, and the
+    ranks' ray counts must add up to the frame's."""
+    import torch
+    import rtamd
+    sc = rtamd.material_grid_scene(100, 100)
+    w, h, depth, world = 3840, 2160, 8, 8
+    dev = torch.device("cuda", 0)
+    whole = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    parts = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    with rtamd.DeviceScene(sc) as ds:
+        ds.render_device(whole.data_ptr(), None, w, h, max_depth=depth, dev_ray_count=cnt.data_ptr())
+        torch.cuda.synchronize()
+        n_whole = int(cnt.item())
+        shares = []
+        for rank in range(world):
+            cnt.zero_()
+            ds.render_device(parts.data_ptr(), None, w, h, max_depth=depth, band_rows=8,
+                             band_index=rank, band_count=world, dev_ray_count=cnt.data_ptr())
+            torch.cuda.synchronize()
+            assert not ds.queue_overflowed()
+            shares.append(int(cnt.item()))
+    assert sum(shares) == n_whole
+    assert max(shares) < 1.1 * n_whole / world      # the interleaved bands balance the ranks
+    assert torch.equal(whole, parts)
