@@ -204,6 +204,16 @@ int rt_render_device_selfcheck(rt_scene *scene, const camera *cam,
                                const rt_frame *frame, uint64_t *dev_ray_count,
                                uint64_t *dev_stats);
 
+/* Host-only self-check of the hierarchy builders (no GPU needed): builds the
+ * sphere and the triangle hierarchy for the scene and counts violated
+ * invariants.  out (8 x int64): [0] sphere nodes (-1: no hierarchy), [1] spheres
+ * sticking out of an ancestor box, [2] distance bounds above the true distance,
+ * [3] primitives missing from or duplicated in a hierarchy, [4] triangle nodes
+ * (-1: none), [5] triangles kept outside the hierarchy, [6] triangle corners
+ * outside an ancestor sphere, [7] triangle normals outside an ancestor cone.
+ * [1..3] and [6..7] must be 0.  No counterpart in the reference.             */
+int rt_host_check_hierarchies(const scene_desc *scene, int64_t *out);
+
 /* Bulk form of check_intersection (renderer.hpp:21-23): n rays, host arrays.
  * orig/dir are 3*n floats; kind (0 none / 1 triangle / 2 sphere), index
  * (class-local, untouched semantics -> -1 on miss) are n int32; P is 3*n

@@ -13,6 +13,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -695,6 +698,142 @@ int rt_scene_set_rays_per_pixel(rt_scene *S, int n) {
   if (n < 1 || n > 256)
     return fail(RT_ERR_BAD_ARG, "rays per pixel %d outside 1..256", n);
   S->rays_per_pixel = n;
+  return RT_OK;
+}
+
+// Host-only self-check of the two hierarchy builders (no HIP call): walks each
+// tree and counts violated invariants in double precision.
+int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
+  int rc = check_scene_desc(s);
+  if (rc)
+    return rc;
+  if (!out)
+    return fail(RT_ERR_BAD_ARG, "out is NULL");
+  for (int k = 0; k < 8; k++)
+    out[k] = 0;
+  // ---- spheres: boxes ----
+  {
+    rt::BvhHost H;
+    rt::bvh_build(s->spheres, s->radius, s->s_size, H);
+    out[0] = H.valid ? (int64_t)H.nodes.size() : -1;
+    if (H.valid) {
+      std::vector<int> seen(s->s_size, 0);
+      struct Item {
+        int node;
+        std::vector<std::pair<float4, float4>> boxes; // ancestors' child entries
+      };
+      std::vector<Item> todo;
+      todo.push_back(Item{0, {}});
+      while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        const rt::BvhNode &N = H.nodes[it.node];
+        for (int c = 0; c < rt::BVH_WIDTH; c++) {
+          int32_t link;
+          memcpy(&link, &N.b[c].w, 4);
+          if (link == rt::BVH_EMPTY)
+            continue;
+          auto boxes = it.boxes;
+          boxes.push_back({N.a[c], N.b[c]});
+          if (link >= 0) {
+            todo.push_back(Item{link, boxes});
+            continue;
+          }
+          const int idx = H.leaf_idx[(~link) >> 3];
+          seen[idx]++;
+          const double r = std::fabs((double)s->radius[idx]);
+          for (auto &bx : boxes) {
+            const double lo[3] = {bx.first.x, bx.first.y, bx.first.z};
+            const double hi[3] = {bx.first.w, bx.second.x, bx.second.y};
+            double d2 = 0;
+            for (int d = 0; d < 3; d++) {
+              const double cc = s->spheres[3 * idx + d];
+              if (cc - r < lo[d] || cc + r > hi[d])
+                out[1]++; // sphere sticks out of an ancestor box
+              const double g = lo[d] > 0 ? lo[d] : (hi[d] < 0 ? -hi[d] : 0.0);
+              d2 += g * g;
+            }
+            if ((double)bx.second.z > std::sqrt(d2))
+              out[2]++; // distance bound above the true distance
+          }
+        }
+      }
+      for (int i = 0; i < s->s_size; i++)
+        if (seen[i] != 1)
+          out[3]++; // sphere missing or duplicated
+    }
+  }
+  // ---- triangles: spheres + normal cones ----
+  {
+    rt::TriBvhHost H;
+    rt::tri_bvh_build(s->tris, s->t_size, H);
+    out[4] = H.valid ? (int64_t)H.nodes.size() : -1;
+    out[5] = (int64_t)H.loose.size();
+    if (H.valid && !H.nodes.empty()) {
+      std::vector<int> seen(s->t_size, 0);
+      for (int i : H.loose)
+        seen[i]++;
+      struct Item {
+        int node;
+        std::vector<std::pair<float4, uint2>> bounds;
+      };
+      std::vector<Item> todo;
+      todo.push_back(Item{0, {}});
+      while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        const rt::TriNode &N = H.nodes[it.node];
+        for (int c = 0; c < rt::BVH_WIDTH; c++) {
+          const int32_t link = N.link[c];
+          if (link == rt::BVH_EMPTY)
+            continue;
+          auto bounds = it.bounds;
+          bounds.push_back({N.s[c], N.ns[c]});
+          if (link >= 0) {
+            todo.push_back(Item{link, bounds});
+            continue;
+          }
+          const int idx = H.leaf_idx[(~link) >> 3];
+          seen[idx]++;
+          const float *p = s->tris + 9 * (size_t)idx;
+          // the triangle's unit normal, in double
+          const double ax = (double)p[3] - p[0], ay = (double)p[4] - p[1], az = (double)p[5] - p[2];
+          const double bx = (double)p[6] - p[0], by = (double)p[7] - p[1], bz = (double)p[8] - p[2];
+          double n[3] = {ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx};
+          const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+          for (auto &bd : bounds) {
+            for (int k = 0; k < 3; k++) {
+              const double dx = p[3 * k] - (double)bd.first.x, dy = p[3 * k + 1] - (double)bd.first.y,
+                           dz = p[3 * k + 2] - (double)bd.first.z;
+              if (std::sqrt(dx * dx + dy * dy + dz * dz) > (double)bd.first.w)
+                out[6]++; // corner outside an ancestor sphere
+            }
+            // unpack the node normal and spread as the device does
+            const double u[3] = {(double)(int16_t)(bd.second.x & 0xffffu) / 32767.0,
+                                 (double)(int16_t)(bd.second.x >> 16) / 32767.0,
+                                 (double)(int16_t)(bd.second.y & 0xffffu) / 32767.0};
+            const uint32_t hb = bd.second.y >> 16;
+            const int he = (hb >> 10) & 31, hm = hb & 1023;
+            const double spread = he == 0 ? hm * std::ldexp(1.0, -24)
+                                          : (he == 31 ? INFINITY : (1.0 + hm / 1024.0) * std::ldexp(1.0, he - 15));
+            if (nl > 0) {
+              const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+              double dm = 0, dp = 0;
+              for (int k = 0; k < 3; k++) {
+                dm += (n[k] / nl - u[k] / ul) * (n[k] / nl - u[k] / ul);
+                dp += (n[k] / nl + u[k] / ul) * (n[k] / nl + u[k] / ul);
+              }
+              if (std::sqrt(std::min(dm, dp)) > spread + 1e-5)
+                out[7]++; // normal outside an ancestor cone (1e-5: float normal vs this double one)
+            }
+          }
+        }
+      }
+      for (int i = 0; i < s->t_size; i++)
+        if (seen[i] > 1)
+          out[3]++; // triangle in two places
+    }
+  }
   return RT_OK;
 }
 

@@ -1,0 +1,73 @@
+"""The hierarchy builders are host code (csrc/rt_bvh.cpp, csrc/rt_tribvh.cpp).
+rt_host_check_hierarchies builds both trees for a scene without touching a GPU
+and counts violated invariants: every sphere inside all its ancestor boxes, every
+triangle corner inside all its ancestor spheres, every triangle normal inside
+its ancestors' normal cones, distance bounds that are true lower bounds, every
+primitive in exactly one place."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_scenes
+import rtamd
+
+sys.path.insert(0, os.path.join(rtamd.REPO_DIR, "tools"))
+import fuzz_parity  # noqa: E402
+
+
+def check(sc):
+    out = (C.c_int64 * 8)()
+    d = sc.desc()
+    fn = rtamd.lib().rt_host_check_hierarchies
+    fn.argtypes = [C.POINTER(rtamd.SceneDesc), C.POINTER(C.c_int64)]
+    assert fn(C.byref(d), out) == 0
+    return list(out)
+
+
+def assert_sound(o):
+    assert o[1] == 0 and o[2] == 0 and o[3] == 0 and o[6] == 0 and o[7] == 0, o
+
+
+def test_grids_and_mixed_scenes():
+    for sc in (rtamd.grid_scene(10, 10), rtamd.grid_scene(30, 30), rtamd.grid_scene(100, 100),
+               golden_scenes.mixed_scene(), golden_scenes.mixed_scene(seed=9, n_spheres=500, n_tris=40)):
+        o = check(sc)
+        assert_sound(o)
+        assert o[0] > 0
+    o = check(rtamd.grid_scene(100, 100))
+    assert o[0] == 5461      # 4^0 + ... + 4^6 nodes over 10 000 single-sphere leaves
+
+
+@pytest.mark.parametrize("rough", [0.0, 1.5, 6.0])
+def test_meshes(rough):
+    sc = rtamd.mesh_scene(80, 60, grid=6, roughness=rough)
+    o = check(sc)
+    assert_sound(o)
+    assert o[4] > sc.t_size // 4 and o[5] == 0            # all 9 600 triangles in the tree
+
+
+def test_awkward_triangles_stay_outside_the_tree():
+    rng = np.random.RandomState(3)
+    base = rtamd.mesh_scene(10, 10, grid=3)
+    extra = []
+    for k in range(30):   # slivers
+        p = rng.uniform(-30, 30, 3) + [0, 0, -60]
+        extra.append(np.concatenate([p, p + rng.normal(size=3) * 20, p + rng.normal(size=3) * 1e-4]))
+    extra.append(np.zeros(9))
+    extra.append(np.array([0, 0, -40, 1e20, 0, -40, 0, 1e20, -40]))
+    extra.append(np.array([np.nan, 0, -40, 3, 0, -40, 0, 5, -40]))
+    tris = np.concatenate([base.tris, np.array(extra, np.float32)])
+    col = np.concatenate([base.color_tri, np.zeros((len(extra), 3), np.uint8)])
+    sc = rtamd.Scene(tris, col, base.spheres, base.radius, base.color_sphere, base.lights)
+    o = check(sc)
+    assert_sound(o)
+    assert o[5] >= 25        # the slivers and the huge one are tested by every ray instead
+
+
+def test_random_scenes():
+    for seed in range(300, 340):
+        sc, _, _ = fuzz_parity.scene(seed)
+        assert_sound(check(sc))
