@@ -199,3 +199,29 @@ def test_million_triangles_8k_depth8_pixel_sample(oracle):
     assert np.array_equal(got_ids, want_ids)
     assert np.array_equal(got, want)
     assert ((want_ids >= 0) & (want_ids < sc.t_size)).sum() > 50
+
+
+def test_mesh_scene_against_the_reference():
+    """The same 2 000-triangle scene the real reference rendered at 2560x1440
+    (tests/golden/golden_mesh_v1.npz): the frame through the triangle hierarchy
+    must have the reference's row CRCs, framebuffer and hit ids, and
+    check_intersection the reference's kind / index / P bits on 20 000 rays."""
+    import os
+    import sys
+    import zlib
+    sys.path.insert(0, os.path.join(rtamd.REPO_DIR, "oracle"))
+    import gen_golden_mesh
+    g = np.load(os.path.join(rtamd.REPO_DIR, "tests", "golden", "golden_mesh_v1.npz"))
+    sc = gen_golden_mesh.mesh()
+    assert sc.t_size == 2000
+    fb, ids, n = rtamd.render(sc, 2560, 1440)
+    crc = lambda a: np.array([zlib.crc32(np.ascontiguousarray(a[i]).tobytes()) for i in range(a.shape[0])], np.uint32)
+    assert np.array_equal(crc(ids), g["mesh_idcrc"])
+    assert np.array_equal(crc(fb), g["mesh_fbcrc"])
+    o, d = gen_golden_mesh.mesh_rays(sc)
+    with rtamd.DeviceScene(sc) as ds:
+        kind, index, P = ds.check_intersection(o, d)
+    assert np.array_equal(kind, g["mesh_rays_kind"].astype(np.int32))
+    m = kind != 0
+    assert np.array_equal(index[m], g["mesh_rays_index"][m])
+    assert np.array_equal(P.view(np.uint32)[m], g["mesh_rays_P"][m])
