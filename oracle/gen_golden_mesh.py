@@ -8,8 +8,9 @@ Run in the build container only (needs oracle/_ref/libref.so):
 
     make -C oracle && python oracle/gen_golden_mesh.py
 
-Written: per-row CRC32 of framebuffer and hit-id buffer, and kind / index / P
-bits of 20 000 rays.  Inputs are seeded (rtamd.mesh_scene, the ray generator
+Written: per-row CRC32 of framebuffer and hit-id buffer, kind / index / P bits
+of 20 000 rays, and the row CRCs of the reference's render of its own largest
+benchmark scene, the 100 x 100 sphere grid.  Inputs are seeded (rtamd.mesh_scene, the ray generator
 below); no reference source text is stored."""
 import os
 import sys
@@ -63,6 +64,13 @@ def main():
     out["mesh_rays_index"] = index.astype(np.int32)
     out["mesh_rays_P"] = P.view(np.uint32)
     print("rays: triangle hits %d, sphere hits %d of %d" % ((kind == 1).sum(), (kind == 2).sum(), len(kind)))
+    # the reference's own largest benchmark scene (BENCHMAX, main.cpp:372-375):
+    # the 100 x 100 sphere grid, which is also the bench scene of this repository
+    g100 = rtamd.grid_scene(100, 100)
+    fb = ref.render(g100)
+    ids = ref.hit_ids(g100)
+    out["g100_fbcrc"], out["g100_idcrc"] = row_crc(fb), row_crc(ids)
+    print("g100: sphere pixels %.3f" % (ids >= g100.t_size).mean())
     path = os.path.join(HERE, "..", "tests", "golden", "golden_mesh_v1.npz")
     np.savez_compressed(path, **out)
     print("wrote", os.path.normpath(path), os.path.getsize(path), "bytes")

@@ -370,3 +370,21 @@ def test_axis_parallel_rays_on_box_faces(oracle):
         hit = k0 != 0
         assert np.array_equal(i0[hit], i1[hit]), mode
         assert np.array_equal(p0.view(np.uint32)[hit], p1.view(np.uint32)[hit]), mode
+
+
+def test_10k_grid_against_the_reference():
+    """The reference's own largest benchmark scene (100 x 100 spheres, BENCHMAX
+    in its CMakeLists) rendered by the real reference at 2560x1440
+    (tests/golden/golden_mesh_v1.npz): every row of the framebuffer and of the
+    hit-id buffer must have the reference's CRC, in every mode."""
+    import os
+    g = np.load(os.path.join(rtamd.REPO_DIR, "tests", "golden", "golden_mesh_v1.npz"))
+    sc = rtamd.grid_scene(100, 100)
+    for mode in ("auto", "beam", "bvh"):
+        try:
+            rtamd.set_screen(mode)
+            fb, ids, n = rtamd.render(sc, W, H)
+        finally:
+            rtamd.set_screen("auto")
+        assert np.array_equal(row_crc(ids), g["g100_idcrc"]), mode
+        assert np.array_equal(row_crc(fb), g["g100_fbcrc"]), mode
