@@ -150,9 +150,25 @@ struct Builder {
     return B;
   }
 
+  // longest axis of the centroids' box of order[b, e): all a split needs
+  int split_axis(int b, int e) const {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = b; k < e; k++) {
+      const Tri &T = tri[order[k]];
+      for (int d = 0; d < 3; d++) {
+        lo[d] = std::min(lo[d], T.c[d]);
+        hi[d] = std::max(hi[d], T.c[d]);
+      }
+    }
+    int axis = 0;
+    for (int d = 1; d < 3; d++)
+      if (hi[d] - lo[d] > hi[axis] - lo[axis])
+        axis = d;
+    return axis;
+  }
+
   void split(int b, int e, int &m) {
-    int axis;
-    (void)bound(b, e, axis);
+    const int axis = split_axis(b, e);
     m = b + (e - b) / 2;
     std::nth_element(order.begin() + b, order.begin() + m, order.begin() + e,
                      [&](int32_t x, int32_t y) {
