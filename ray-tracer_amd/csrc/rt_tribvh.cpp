@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <future>
 #include <numeric>
 
 namespace rt {
@@ -48,11 +49,18 @@ struct Tri {
   double extra;  // how far the corners leave the plane N.(x - p1) = 0
 };
 
+// Builds the subtree of a range of `order` into `nodes` / `leaves`, numbering both
+// from wherever those vectors stand.  Several builders may work on disjoint
+// ranges of the same `order` at once, each into vectors of its own.
 struct Builder {
-  const float *v; // 9 floats per triangle
-  std::vector<Tri> tri;
-  std::vector<int32_t> order; // positions in `tri`
-  TriBvhHost *out;
+  const float *v;              // 9 floats per triangle
+  const std::vector<Tri> &tri;
+  std::vector<int32_t> &order; // positions in `tri`
+  std::vector<TriNode> *nodes;
+  std::vector<int32_t> *leaves;
+  Builder(const float *v_, const std::vector<Tri> &t, std::vector<int32_t> &o,
+          std::vector<TriNode> *n, std::vector<int32_t> *l)
+      : v(v_), tri(t), order(o), nodes(n), leaves(l) {}
 
   struct Bound {
     float4 s;
@@ -177,12 +185,16 @@ struct Builder {
                      });
   }
 
-  int32_t build(int b, int e, Bound &me_bound) {
+  // par: levels of the recursion whose children are built by tasks of their own
+  // (ranges above 32768 triangles only).  The tasks build into private vectors,
+  // which are then appended in child order with their links shifted: exactly the
+  // numbering of the sequential depth-first build.
+  int32_t build(int b, int e, Bound &me_bound, int par = 0) {
     int axis;
     me_bound = bound(b, e, axis);
     if (e - b == 1) {
-      const int slot = (int)out->leaf_idx.size();
-      out->leaf_idx.push_back(tri[order[b]].index);
+      const int slot = (int)leaves->size();
+      leaves->push_back(tri[order[b]].index);
       return ~(slot << 3);
     }
     int m;
@@ -203,20 +215,44 @@ struct Builder {
         hi[parts++] = he;
       }
     }
-    const int me = (int)out->nodes.size();
-    out->nodes.push_back(TriNode{});
+    const int me = (int)nodes->size();
+    nodes->push_back(TriNode{});
     Bound cb[BVH_WIDTH];
     int32_t cl[BVH_WIDTH];
-    for (int k = 0; k < BVH_WIDTH; k++) {
-      if (k < parts) {
-        cl[k] = build(lo[k], hi[k], cb[k]);
-      } else {
-        cl[k] = BVH_EMPTY;
-        cb[k].s = make_float4(0.f, 0.f, 0.f, 0.f);
-        cb[k].ns = make_uint2(0u, 0u);
-      }
+    for (int k = parts; k < BVH_WIDTH; k++) {
+      cl[k] = BVH_EMPTY;
+      cb[k].s = make_float4(0.f, 0.f, 0.f, 0.f);
+      cb[k].ns = make_uint2(0u, 0u);
     }
-    TriNode &N = out->nodes[me];
+    if (par > 0 && e - b > 32768) {
+      std::vector<TriNode> sub_nodes[BVH_WIDTH];
+      std::vector<int32_t> sub_leaves[BVH_WIDTH];
+      std::future<int32_t> done[BVH_WIDTH];
+      for (int k = 0; k < parts; k++)
+        done[k] = std::async(std::launch::async, [&, k]() {
+          Builder sub(v, tri, order, &sub_nodes[k], &sub_leaves[k]);
+          return sub.build(lo[k], hi[k], cb[k], par - 1);
+        });
+      for (int k = 0; k < parts; k++) {
+        int32_t link = done[k].get();
+        const int node_off = (int)nodes->size(), leaf_off = (int)leaves->size();
+        auto shift = [&](int32_t l) -> int32_t {
+          if (l == BVH_EMPTY)
+            return l;
+          return l >= 0 ? l + node_off : ~((((~l) >> 3) + leaf_off) << 3);
+        };
+        for (TriNode &N : sub_nodes[k])
+          for (int c = 0; c < BVH_WIDTH; c++)
+            N.link[c] = shift(N.link[c]);
+        cl[k] = shift(link);
+        nodes->insert(nodes->end(), sub_nodes[k].begin(), sub_nodes[k].end());
+        leaves->insert(leaves->end(), sub_leaves[k].begin(), sub_leaves[k].end());
+      }
+    } else {
+      for (int k = 0; k < parts; k++)
+        cl[k] = build(lo[k], hi[k], cb[k], 0);
+    }
+    TriNode &N = (*nodes)[me];
     for (int k = 0; k < BVH_WIDTH; k++) {
       N.s[k] = cb[k].s;
       N.ns[k] = cb[k].ns;
@@ -235,10 +271,9 @@ void tri_bvh_build(const float *tris, int n, TriBvhHost &out) {
   out.valid = false;
   if (n <= 0)
     return;
-  Builder B;
-  B.v = tris;
-  B.out = &out;
-  B.tri.reserve(n);
+  std::vector<Tri> fit;
+  std::vector<int32_t> order;
+  fit.reserve(n);
   for (int i = 0; i < n; i++) {
     const float *p = tris + 9 * (size_t)i;
     float Nf[3];
@@ -299,15 +334,16 @@ void tri_bvh_build(const float *tris, int n, TriBvhHost &out) {
       out.loose.push_back(i);
       continue;
     }
-    B.tri.push_back(T);
+    fit.push_back(T);
   }
-  const int m = (int)B.tri.size();
+  const int m = (int)fit.size();
   out.valid = true;
   if (m == 0)
     return; // everything is loose or unhittable: no nodes
-  B.order.resize(m);
-  std::iota(B.order.begin(), B.order.end(), 0);
+  order.resize(m);
+  std::iota(order.begin(), order.end(), 0);
   out.leaf_idx.reserve(m);
+  Builder B(tris, fit, order, &out.nodes, &out.leaf_idx);
   Builder::Bound root;
   if (m == 1) {
     out.nodes.push_back(TriNode{});
@@ -319,7 +355,7 @@ void tri_bvh_build(const float *tris, int n, TriBvhHost &out) {
       N.link[k] = k == 0 ? l : BVH_EMPTY;
     }
   } else {
-    (void)B.build(0, m, root); // node 0 is the root
+    (void)B.build(0, m, root, 2); // node 0 is the root; up to 16 tasks
   }
 }
 
