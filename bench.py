@@ -112,8 +112,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames rendered concurrently, each on its own stream with its own "
                          "resident scene copy (1 = strictly one frame at a time)")
-    ap.add_argument("--lanes", type=int, default=None,
-                    help="sub-frames in flight inside one rt_render_device call (rt_set_lanes)")
+    ap.add_argument("--side-stream", type=int, default=None, choices=[0, 1],
+                    help="shadow walks of a level on a side stream (default: on with one frame "
+                         "in flight, off with several)")
     args = ap.parse_args()
 
     import torch
@@ -144,9 +145,7 @@ def main():
     band_rows = args.band_rows
     plan = BandPlan(h, w, band_rows, rank, world)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    rtamd.set_screen(args.screen)
-    if args.lanes is not None:
-        rtamd.lib().rt_set_lanes(args.lanes)
+    rtamd.set_screen(args.screen)   # the mode scenes created below start with
     # Frames in flight: a frame is a chain of ~16 dependent launches, each ending
     # with a few long rays, so one frame alone cannot keep the chip busy once its
     # share of the rays is small (N > 1).  Each slot has its own resident copy of
@@ -155,7 +154,7 @@ def main():
     n_buf = max(1, args.frames_in_flight)
     # several frames in flight: one stream per frame, no side streams inside a
     # frame (the device has 4 hardware queues; streams sharing one serialise)
-    rtamd.lib().rt_set_side_stream(1 if n_buf == 1 else 0)
+    side = args.side_stream if args.side_stream is not None else (1 if n_buf == 1 else 0)
 
     class Slot:
         pass
@@ -163,6 +162,7 @@ def main():
     for _ in range(n_buf):
         sl = Slot()
         sl.scene = rtamd.DeviceScene(sc)
+        sl.scene.set_side_stream(side)
         sl.stream = torch.cuda.Stream(device=dev)
         sl.fb = plan.alloc_frame(dev)
         sl.send, sl.recv = plan.alloc_gather(comm_dev)
@@ -280,14 +280,16 @@ def main():
         elif world == 1 and args.screen != "off":
             # the same frame with the screen off: the brute-force formulation the
             # FP32 roofline is defined on (every ray against every primitive)
-            rtamd.set_screen(False)
+            for sl in slots:
+                sl.scene.set_screen("off")
             step(False)
             torch.cuda.synchronize()
             events.clear()
             for _ in range(2):
                 step(True)
             torch.cuda.synchronize()
-            rtamd.set_screen(args.screen)
+            for sl in slots:
+                sl.scene.set_screen(args.screen)
             bf_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
             bf = my_rays_per_launch * n_tests_per_ray / (bf_ms * 1e-3) / 1e12
             out["roofline"]["plain_loop"] = {

@@ -36,7 +36,7 @@ typedef enum rt_status {
   RT_ERR_BAD_ARG = -1,      /* null pointer, negative size, w/h <= 0 ... */
   RT_ERR_NO_DEVICE = -2,    /* no HIP device visible */
   RT_ERR_HIP = -3,          /* a HIP runtime call failed */
-  RT_ERR_CAPACITY = -4,     /* secondary-ray queue could not be sized */
+  RT_ERR_CAPACITY = -4,     /* a fixed-size buffer is too small for the request */
   RT_ERR_UNSUPPORTED = -5
 } rt_status;
 
@@ -105,6 +105,22 @@ int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
                    int32_t *hit_ids, uint64_t *n_rays, int w, int h,
                    int max_depth);
 
+/* As gpu_render for the reference built with -DUNLIT=1 (renderer.cpp:78,
+ * 130-137): flat colour of the hit primitive, no lights.                     */
+int gpu_render_unlit(const scene_desc *scene, const camera *cam, uint8_t *rgb,
+                     int w, int h);
+
+/* gpu_render, gpu_render_ids, gpu_render_unlit and gpu_render_multi keep the
+ * device copy of the last scene they were given (per device): a later call with
+ * the same array pointers, sizes and contents (all bytes are hashed) skips the
+ * upload and the hierarchy builds; anything else replaces the kept scene.
+ * rt_cache_clear releases it.  The `map(to:)` of renderer.cpp:13-21 happens once
+ * per distinct scene, not once per frame.                                    */
+void rt_cache_clear(void);
+/* How many scenes those entry points have built so far in this process
+ * (diagnostic: lets a host or a test see that a call reused the kept scene).  */
+uint64_t rt_cache_builds(void);
+
 /* ---- resident scene + device-side rendering -------------------------------
  * The `map(to: ...)` clause of renderer.cpp:13-21 as an explicit object: the
  * flat arrays are uploaded once, re-laid-out for the kernels, and stay in HBM
@@ -125,8 +141,14 @@ typedef struct rt_frame {
   int32_t band_rows;    /* rows per band, > 0 (ignored when band_count = 1) */
   int32_t band_index;
   int32_t band_count;
+  int32_t flags;        /* 0 or RT_FRAME_UNLIT */
   void *stream;         /* hipStream_t or NULL for the default stream */
 } rt_frame;
+
+/* rt_frame.flags: the reference built with -DUNLIT=1 (renderer.cpp:78,130-137;
+ * CMakeLists.txt:36): a hit pixel gets its primitive's colour, no lights, no
+ * shadow rays, no bounces (max_depth is ignored).                             */
+#define RT_FRAME_UNLIT 1
 
 /* Enqueues the render of `frame` on frame->stream and returns without
  * waiting.  Pixels outside this call's bands are not touched.
@@ -134,9 +156,12 @@ typedef struct rt_frame {
 int rt_render_device(rt_scene *scene, const camera *cam, const rt_frame *frame,
                      uint64_t *dev_ray_count);
 
-/* Bounce rays wait in a queue in HBM sized at 4 rays per pixel of the call.  If a
- * scene spawns more, the excess is dropped and this reports 1 (blocking read;
- * gpu_render/gpu_render_ids check it themselves and return RT_ERR_CAPACITY).  */
+/* Bounce rays wait in a queue in HBM sized at 4 rays per pixel of the call (see
+ * rt_scene_set_rays_per_pixel).  If a frame spawns more, the excess is dropped
+ * and this reports 1 after the frame (blocking read): the image is incomplete.
+ * gpu_render / gpu_render_ids check it themselves, enlarge the queue and render
+ * again; they return RT_ERR_CAPACITY only if the largest queue overflows too,
+ * which the weight cut-off makes impossible.                                  */
 int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
 
 /* Capacity of the bounce-ray queues of later rt_render_device calls: n rays per
@@ -150,7 +175,7 @@ int rt_scene_set_rays_per_pixel(rt_scene *scene, int n);
 
 /* ---- work avoidance (no counterpart in the reference) ----------------------
  * The reference tests every ray against every primitive (renderer.cpp:156-177).
- * The library gets the same answers with far fewer tests, in two ways:
+ * The library gets the same answers with far fewer tests, in three ways:
  *   - beam screen: a wave's rays that share an apex (primary rays: the eye;
  *     shadow rays: the light) are bounded by a cone, the spheres are screened
  *     64 at a time (one per lane) against that cone, and the reference's per-ray
@@ -167,28 +192,21 @@ int rt_scene_set_rays_per_pixel(rt_scene *scene, int n);
  * identical in every mode.  mode: 0 = plain loop, every ray against every
  * primitive (used to measure the brute-force roofline); 1 = automatic (default);
  * 2 = beam screen for primary/shadow rays; 3 = hierarchy for all rays.
- * Process-wide; not thread-safe against concurrent renders.                   */
+ * The mode belongs to a scene: rt_scene_set_screen changes it for later frames
+ * of that scene; rt_set_screen sets the mode that scenes created afterwards
+ * start with (gpu_render* create theirs inside the call).                     */
 void rt_set_screen(int mode);
 int rt_get_screen(void);
-
-/* A frame with bounces (max_depth > 1) can be rendered as n independent
- * sub-frames of alternate row bands, each a chain of launches on its own stream
- * with its own queues.  n = 1..4, default 1 (more chains were measured to bring
- * no gain on this chip: the walk kernels are bound by instruction issue).
- * Results do not depend on n.  No counterpart in the reference.  Process-wide,
- * like rt_set_screen.                                                         */
-void rt_set_lanes(int n);
-int rt_get_lanes(void);
+int rt_scene_set_screen(rt_scene *scene, int mode);
 
 /* Within one frame the shadow walks of a bounce level run on a side stream owned
  * by the scene, beside the next level's nearest-hit walks (default, on: one frame
  * at a time is 10 % faster that way).  A caller that keeps several frames in
- * flight on streams of its own should turn it off: the device has 4 hardware
- * queues, and streams that share one serialise (3 frames in flight on one
- * MI355X: 7.8 ms per depth-8 frame without, 8.1 ms with).  Results do not depend
- * on it.  No counterpart in the reference.  Process-wide.                      */
-void rt_set_side_stream(int on);
-int rt_get_side_stream(void);
+ * flight on streams of its own should turn it off for those scenes: the device
+ * has 4 hardware queues, and streams that share one serialise (3 frames in flight
+ * on one MI355X: 7.8 ms per depth-8 frame without, 8.1 ms with).  Results do not
+ * depend on it.  No counterpart in the reference.                              */
+int rt_scene_set_side_stream(rt_scene *scene, int on);
 
 /* As rt_render_device, with a slow self-checking build of the kernel that
  * re-tests every sphere the screen dropped.  dev_stats (device, 16 x uint64,
@@ -221,6 +239,38 @@ int rt_host_check_hierarchies(const scene_desc *scene, int64_t *out);
 int gpu_check_intersection(rt_scene *scene, int64_t n, const float *orig,
                            const float *dir, int32_t *kind, int32_t *index,
                            float *P);
+
+/* check_intersection as the reference's own callers use it (renderer.hpp:21-23:
+ * the scene arrays and ONE ray per call): the scene is kept resident exactly as
+ * gpu_render keeps it, so only the first call for a set of arrays uploads and
+ * builds.  Colours play no part: scene->color_tri / color_sphere may be NULL.
+ * kind, index, P: one element (three floats for P), semantics as above.      */
+int gpu_check_intersection_arrays(const scene_desc *scene, const float *orig,
+                                  const float *dir, int32_t *kind,
+                                  int32_t *index, float *P);
+
+/* ---- several GPUs of one process -------------------------------------------
+ * The OpenMP offload contract of renderer.cpp:13-30 (scene `map(to:)` every
+ * worker, rows in parallel, framebuffer rows `map(from:)` back) on n_devices
+ * GPUs driven by the calling thread: the scene is made resident on devices
+ * 0..n_devices-1 (kept as gpu_render keeps it), bands of band_rows rows
+ * (a positive multiple of 8) are dealt round-robin (band b -> device
+ * b % n_devices), every device renders its bands on a stream of its own, the
+ * bands travel to device 0 peer to peer over xGMI (hipMemcpyPeerAsync), and
+ * device 0 hands the whole frame to `rgb` / `hit_ids` (host; hit_ids and n_rays
+ * may be NULL).  Blocking, like render().  n_devices = 1 is gpu_render_ids.  */
+int gpu_render_multi(const scene_desc *scene, const camera *cam, uint8_t *rgb,
+                     int32_t *hit_ids, uint64_t *n_rays, int w, int h,
+                     int max_depth, int n_devices, int band_rows);
+
+/* The band bookkeeping of the sharded entry points, for hosts that move the
+ * bands themselves: rows [row_begin[k], row_end[k]) for k < return value are the
+ * bands of a frame of h rows that share `band_index` of `band_count` owns
+ * (band b covers rows b*band_rows ...; b % band_count == band_index).  Writes at
+ * most `max_bands` entries; returns the number of owned bands, or a negative
+ * rt_status.  Pure host arithmetic (no GPU needed).                          */
+int rt_band_plan(int h, int band_rows, int band_index, int band_count,
+                 int32_t *row_begin, int32_t *row_end, int max_bands);
 
 /* ---- misc ---------------------------------------------------------------- */
 const char *rt_last_error(void);

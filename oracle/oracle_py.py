@@ -19,6 +19,7 @@ import rtamd  # noqa: E402  (struct definitions and the Scene container only)
 
 ORACLE_PATH = os.path.join(_HERE, "liboracle.so")
 REF_PATH = os.path.join(_HERE, "_ref", "libref.so")
+REF_UNLIT_PATH = os.path.join(_HERE, "_ref", "libref_unlit.so")  # the reference with -DUNLIT=1
 
 _f32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -30,6 +31,10 @@ class Oracle:
         L.oracle_render.argtypes = [C.POINTER(rtamd.SceneDesc), C.POINTER(rtamd.Camera),
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int]
+        L.oracle_render_unlit.restype = C.c_uint64
+        L.oracle_render_unlit.argtypes = [C.POINTER(rtamd.SceneDesc), C.POINTER(rtamd.Camera),
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int]
         L.oracle_render_pixels.restype = C.c_uint64
         L.oracle_render_pixels.argtypes = [C.POINTER(rtamd.SceneDesc), C.POINTER(rtamd.Camera),
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -64,6 +69,18 @@ class Oracle:
         n = self.L.oracle_render(C.byref(d), C.byref(cam), fb.ctypes.data,
                                  ids.ctypes.data if want_ids else None, w, h, max_depth,
                                  b, e, s)
+        return fb, ids, int(n)
+
+    def render_unlit(self, scene: rtamd.Scene, w, h, cam=None, rows=None):
+        """The reference's -DUNLIT=1 build (renderer.cpp:130-137).  Returns
+        (fb, ids, n_rays)."""
+        cam = cam or rtamd.default_camera()
+        fb = np.zeros((h, w, 4), np.uint8)
+        ids = np.full((h, w), -2, np.int32)
+        b, e, s = rows or (0, h, 1)
+        d = scene.desc()
+        n = self.L.oracle_render_unlit(C.byref(d), C.byref(cam), fb.ctypes.data,
+                                       ids.ctypes.data, w, h, b, e, s)
         return fb, ids, int(n)
 
     def render_pixels(self, scene: rtamd.Scene, w, h, max_depth, pixels, cam=None):
@@ -152,15 +169,15 @@ class Oracle:
 class Ref:
     """The real reference.  Renders only at its compiled-in 2560x1440."""
 
-    def __init__(self):
-        L = C.CDLL(REF_PATH)
+    def __init__(self, unlit=False):
+        L = C.CDLL(REF_UNLIT_PATH if unlit else REF_PATH)
         self.L = L
         self.W = L.ref_canvas_width()
         self.H = L.ref_canvas_height()
 
     @staticmethod
-    def available() -> bool:
-        return os.path.exists(REF_PATH)
+    def available(unlit=False) -> bool:
+        return os.path.exists(REF_UNLIT_PATH if unlit else REF_PATH)
 
     def render(self, scene: rtamd.Scene, fov=90):
         fb = np.zeros((self.H, self.W, 4), np.uint8)

@@ -375,6 +375,13 @@ static uint64_t shade_pixel(const scene_desc *sc, const camera *cam, int w,
     if (hi.kind == 0)
       continue;
     hit_normal_color(sc, &hi);
+    if (max_depth == 0) { /* the UNLIT build, renderer.cpp:130-137 */
+      for (int k = 0; k < 3; k++) {
+        int v = px[k] + hi.color[k];
+        px[k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+      continue;
+    }
 
     /* max_depth = 1 is the reference: materials play no part at all */
     const rt_material *m =
@@ -447,6 +454,15 @@ uint64_t oracle_render(const scene_desc *sc, const camera *cam, uint8_t *fb,
     }
   }
   return total;
+}
+
+/* The reference compiled with -DUNLIT=1 (renderer.cpp:78,130-137): the hit
+ * primitive's colour, no lights, no shadow rays.  Same row selection as
+ * oracle_render. */
+uint64_t oracle_render_unlit(const scene_desc *sc, const camera *cam, uint8_t *fb,
+                             int32_t *ids, int w, int h, int row_begin, int row_end,
+                             int row_step) {
+  return oracle_render(sc, cam, fb, ids, w, h, 0, row_begin, row_end, row_step);
 }
 
 /* The same per-pixel work for a list of n pixels (ij = row, column pairs) of a

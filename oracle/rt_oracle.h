@@ -37,6 +37,9 @@ void oracle_primary_ray(const camera *cam, int w, int h, int i, int j,
 uint64_t oracle_render(const scene_desc *sc, const camera *cam, uint8_t *fb,
                        int32_t *ids, int w, int h, int max_depth,
                        int row_begin, int row_end, int row_step);
+uint64_t oracle_render_unlit(const scene_desc *sc, const camera *cam, uint8_t *fb,
+                             int32_t *ids, int w, int h, int row_begin, int row_end,
+                             int row_step);
 uint64_t oracle_render_pixels(const scene_desc *sc, const camera *cam, uint8_t *out_rgba,
                               int32_t *out_ids, int w, int h, int max_depth, int64_t n,
                               const int32_t *ij);

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -24,7 +26,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
-int g_screen = 1; // rt_set_screen
+std::atomic<int> g_default_screen{1}; // rt_set_screen: mode of scenes created later
 
 int fail(int code, const char *fmt, ...) {
   va_list ap;
@@ -61,50 +63,97 @@ template <typename T> struct DevBuf {
   ~DevBuf() { release(); }
 };
 
-} // namespace
+constexpr int kMaxDepth = 63;       // depth is stored in 6 bits of the ray tag
+constexpr int kBounceBlocks = 2048; // 8 blocks of 256 lanes per CU
+constexpr int kLightGroup = 4;      // lights whose shadow rays share one pass
+constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
+// A bounce ray carries its pixel in the upper 26 bits of a 32-bit tag
+// (pixel << 6 | depth, rt_kernels.hip queue_push).
+constexpr size_t kMaxBouncePixels = (size_t)1 << 26;
 
-// A frame with bounces can be rendered as several independent sub-frames
-// (alternate row bands), each a chain of dependent launches on its own stream
-// with its own queues (rt_set_lanes).  Measured on the 10k-sphere 4K depth-8
-// frame the chains do run concurrently (kernel trace) but the walk kernels are
-// bound by instruction issue, not by idle tails, so nothing is gained: 8.78 ms
-// with 1 lane, 8.80 with 2, 9.92 with 3, 9.69 with 4; 1 is the default.
-constexpr int kMaxLanes = 4;
-int g_lanes = 1;
-int g_side_stream = 1; // rt_set_side_stream
+// What the bounce levels of one frame need besides the scene: ray queues, hit
+// lists, shadow items, control words and the per-pixel integer sums.  All of it
+// is carved out of ONE region of device memory, so that the same launch code
+// runs on a region the scene allocated and on a region a caller provides.
+struct BounceNeeds {
+  size_t capacity = 0;     // rays per level (a multiple of QUEUE_SEGMENTS)
+  int per_ray = 1;         // shadow items per ray and pass
+  bool tri = false;        // hit lists of the triangle walk as well
+  int levels = 0;          // control rows for levels 0 .. levels-1
+  int ctl_rows = 0;        // control rows per level
+  size_t frame_pixels = 0; // per-pixel sums for the whole frame
 
-struct BounceLane {
-  DevBuf<float4> queue[2];
+  bool covers(const BounceNeeds &o) const {
+    return capacity >= o.capacity && per_ray >= o.per_ray && (tri || !o.tri) &&
+           levels >= o.levels && ctl_rows >= o.ctl_rows && frame_pixels >= o.frame_pixels;
+  }
+  void grow_to(const BounceNeeds &o) {
+    capacity = std::max(capacity, o.capacity);
+    per_ray = std::max(per_ray, o.per_ray);
+    tri = tri || o.tri;
+    levels = std::max(levels, o.levels);
+    ctl_rows = std::max(ctl_rows, o.ctl_rows);
+    frame_pixels = std::max(frame_pixels, o.frame_pixels);
+  }
+};
+
+struct BounceArena {
+  BounceNeeds have;
+  float4 *queue[2] = {nullptr, nullptr};
   // control words.  A "row" is one counter per queue segment (QUEUE_SEGMENTS x
   // CTL_WORDS uint32).  Per level: rows {queue length, sphere-walk cursor,
   // triangle-walk cursor}, then per group of lights {shadow items, sphere-walk
   // cursor, triangle-walk cursor}; the very last word is the overflow flag
-  DevBuf<uint32_t> counts;
-  int ctl_rows = 0; // rows per level
-  DevBuf<float4> hit_rec, tri_hit_rec, shadow_items[2]; // shadow items: by level parity
-  DevBuf<int32_t> hit_idx, tri_hit_idx;
-  size_t queue_capacity = 0;
-  // The shadow walks of level L and the nearest-hit walks of level L+1 both
-  // depend only on k_shade of level L, so the shadow walks run on a side stream.
-  hipStream_t main = nullptr; // lanes >= 1; lane 0 runs on the caller's stream
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_end = nullptr;
+  uint32_t *counts = nullptr;
+  float4 *hit_rec = nullptr, *tri_hit_rec = nullptr;
+  float4 *shadow_items[2] = {nullptr, nullptr}; // by level parity
+  int32_t *hit_idx = nullptr, *tri_hit_idx = nullptr;
+  unsigned long long *extra = nullptr; // per pixel, 3 x 21 bits
+  size_t bytes = 0;
 
-  ~BounceLane() {
-    for (int k = 0; k < 2; k++) {
-      if (ev_fork[k])
-        (void)hipEventDestroy(ev_fork[k]);
-      if (ev_join[k])
-        (void)hipEventDestroy(ev_join[k]);
+  // Places the regions for `n` behind `base` (256-byte aligned pieces) and
+  // returns the bytes used; base == nullptr only measures.
+  size_t carve(unsigned char *base, const BounceNeeds &n) {
+    size_t off = 0;
+    auto take = [&](size_t bytes_wanted) {
+      unsigned char *p = base ? base + off : nullptr;
+      off += (bytes_wanted + 255) & ~(size_t)255;
+      return p;
+    };
+    const size_t cap = n.capacity;
+    queue[0] = (float4 *)take(2 * cap * sizeof(float4));
+    queue[1] = (float4 *)take(2 * cap * sizeof(float4));
+    hit_rec = (float4 *)take(cap * sizeof(float4));
+    hit_idx = (int32_t *)take(cap * sizeof(int32_t));
+    tri_hit_rec = (float4 *)take(n.tri ? cap * sizeof(float4) : 0);
+    tri_hit_idx = (int32_t *)take(n.tri ? cap * sizeof(int32_t) : 0);
+    for (int k = 0; k < 2; k++)
+      shadow_items[k] = (float4 *)take(2 * cap * (size_t)n.per_ray * sizeof(float4));
+    counts = (uint32_t *)take(((size_t)n.levels * n.ctl_rows * kRowWords + 1) * sizeof(uint32_t));
+    extra = (unsigned long long *)take(n.frame_pixels * sizeof(unsigned long long));
+    if (base) {
+      have = n;
+      bytes = off;
     }
-    if (ev_end)
-      (void)hipEventDestroy(ev_end);
-    if (side)
-      (void)hipStreamDestroy(side);
-    if (main)
-      (void)hipStreamDestroy(main);
+    return off;
+  }
+  uint32_t *ctl(int level, int row) const {
+    return counts + ((size_t)level * have.ctl_rows + row) * kRowWords;
+  }
+  uint32_t *overflow_flag() const {
+    return counts + (size_t)have.levels * have.ctl_rows * kRowWords;
+  }
+  rt::RayQueue queue_for_level(int level) const {
+    rt::RayQueue q;
+    q.items = queue[level & 1];
+    q.count = ctl(level, 0);
+    q.seg_capacity = (uint32_t)(have.capacity / rt::QUEUE_SEGMENTS);
+    q.overflow = overflow_flag();
+    return q;
   }
 };
+
+} // namespace
 
 struct rt_scene {
   int device = 0;
@@ -121,21 +170,36 @@ struct rt_scene {
   DevBuf<int32_t> tloose;
   bool has_tbvh = false;
   bool has_mat_tri = false, has_mat_sph = false;
+  int screen = 1;      // rt_scene_set_screen
+  int side_stream = 1; // rt_scene_set_side_stream
+  // Eye-relative records (k_prep_eye) are rebuilt only when the eye moves.  The
+  // rebuild runs on the stream of the frame that asks for it; ev_eye lets frames
+  // on other streams wait for it, ev_frame marks the end of the last frame's
+  // launches so that a rebuild does not overtake a frame still reading the old
+  // records.
   bool eye_valid = false;
   float eye[3] = {0, 0, 0};
-  // bounce machinery, allocated on the first max_depth > 1 render
-  BounceLane lanes[kMaxLanes];
+  hipEvent_t ev_eye = nullptr, ev_frame = nullptr;
+  bool frame_recorded = false;
+  // bounce machinery, allocated on the first frame with bounces
+  DevBuf<unsigned char> arena_mem;
+  BounceArena arena;
   // queue capacity per level: this many rays per owned pixel (+ 65536).  No level
   // can hold more than 256 per pixel: every queued ray weighs >= 2^-8 and the
   // weights of one pixel's rays at one level sum to at most 1.
   int rays_per_pixel = 4;
-  DevBuf<unsigned long long> extra; // per pixel, 3 x 21 bits
-  size_t extra_pixels = 0;
-  hipEvent_t ev_begin = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+  // staging for gpu_check_intersection (grow-only)
+  DevBuf<float> chk_in, chk_P;
+  DevBuf<int32_t> chk_out;
 
   ~rt_scene() {
-    if (ev_begin)
-      (void)hipEventDestroy(ev_begin);
+    for (hipEvent_t e : {ev_eye, ev_frame, ev_fork[0], ev_fork[1], ev_join[0], ev_join[1]})
+      if (e)
+        (void)hipEventDestroy(e);
+    if (side)
+      (void)hipStreamDestroy(side);
   }
 
   rt::SceneDev dev() const {
@@ -152,11 +216,11 @@ struct rt_scene {
     d.s_size = s_size;
     d.s_pad = s_pad;
     d.l_size = l_size;
-    const bool use_bvh = has_bvh && g_screen != 0;
+    const bool use_bvh = has_bvh && screen != 0;
     d.bvh = use_bvh ? bvh.p : nullptr;
     d.leaf_geo = use_bvh ? leaf_geo.p : nullptr;
     d.leaf_idx = use_bvh ? leaf_idx.p : nullptr;
-    const bool use_tbvh = has_tbvh && g_screen != 0;
+    const bool use_tbvh = has_tbvh && screen != 0;
     d.tbvh = use_tbvh ? tbvh.p : nullptr;
     d.tleaf = use_tbvh ? tleaf.p : nullptr;
     d.tloose = use_tbvh ? tloose.p : nullptr;
@@ -168,14 +232,16 @@ struct rt_scene {
 
 namespace {
 
-int check_scene_desc(const scene_desc *s) {
+// need_colors false: a geometry-only scene (check_intersection), whose colour
+// arrays may be NULL and are then taken as zeros.
+int check_scene_desc(const scene_desc *s, bool need_colors = true) {
   if (!s)
     return fail(RT_ERR_BAD_ARG, "scene is NULL");
   if (s->t_size < 0 || s->s_size < 0 || s->l_size < 0)
     return fail(RT_ERR_BAD_ARG, "negative primitive or light count");
-  if (s->t_size > 0 && (!s->tris || !s->color_tri))
+  if (s->t_size > 0 && (!s->tris || (need_colors && !s->color_tri)))
     return fail(RT_ERR_BAD_ARG, "t_size > 0 but tris/color_tri is NULL");
-  if (s->s_size > 0 && (!s->spheres || !s->radius || !s->color_sphere))
+  if (s->s_size > 0 && (!s->spheres || !s->radius || (need_colors && !s->color_sphere)))
     return fail(RT_ERR_BAD_ARG, "s_size > 0 but spheres/radius/color_sphere is NULL");
   if (s->l_size > 0 && !s->lights)
     return fail(RT_ERR_BAD_ARG, "l_size > 0 but lights is NULL");
@@ -202,11 +268,14 @@ int ensure_device() {
   return RT_OK;
 }
 
+// src == nullptr uploads zeros.
 template <typename T>
 int upload(DevBuf<T> &dst, const void *src, size_t count) {
   HIP_TRY(dst.alloc(count));
-  if (count)
+  if (count && src)
     HIP_TRY(hipMemcpy(dst.p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  else if (count)
+    HIP_TRY(hipMemset(dst.p, 0, count * sizeof(T)));
   return RT_OK;
 }
 
@@ -307,13 +376,22 @@ int scene_build(rt_scene *S, const scene_desc *s) {
   }
   HIP_TRY(hipStreamSynchronize(nullptr)); // staging buffers die here
   S->eye_valid = false;
+  S->screen = g_default_screen.load();
+  HIP_TRY(hipEventCreateWithFlags(&S->ev_eye, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&S->ev_frame, hipEventDisableTiming));
   return RT_OK;
 }
 
-// Eye-relative records are rebuilt only when the eye moves.
+// Eye-relative records are rebuilt only when the eye moves.  Frames of one
+// scene may come in on different streams: a rebuild waits for the last frame's
+// launches (they read the old records), and every frame waits for the rebuild.
 int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
-  if (S->eye_valid && memcmp(S->eye, cam->origin, sizeof S->eye) == 0)
+  if (S->eye_valid && memcmp(S->eye, cam->origin, sizeof S->eye) == 0) {
+    HIP_TRY(hipStreamWaitEvent(st, S->ev_eye, 0)); // no-op on the stream that built them
     return RT_OK;
+  }
+  if (S->frame_recorded)
+    HIP_TRY(hipStreamWaitEvent(st, S->ev_frame, 0));
   rt::EyeArgs a;
   a.sph_geo = S->sph_geo.p;
   a.sph_prim = S->sph_prim.p;
@@ -325,74 +403,50 @@ int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
   a.oy = cam->origin[1];
   a.oz = cam->origin[2];
   HIP_TRY(rt::launch_prep_eye(a, st));
+  HIP_TRY(hipEventRecord(S->ev_eye, st));
   memcpy(S->eye, cam->origin, sizeof S->eye);
   S->eye_valid = true;
   return RT_OK;
 }
 
-constexpr int kMaxDepth = 63;       // depth is stored in 6 bits of the ray tag
-constexpr int kBounceBlocks = 2048; // 8 blocks of 256 lanes per CU
-
-constexpr int kLightGroup = 4; // lights whose shadow rays share one pass
-constexpr int kLevels = 66; // levels 0..65 (depth <= 63, +1 for the last spawn target)
-constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
-
-int ensure_bounce_buffers(rt_scene *S, BounceLane *B, bool own_stream, size_t frame_pixels,
-                          size_t owned_pixels) {
+// What a frame's bounce levels need (see BounceNeeds).
+BounceNeeds bounce_needs(const rt_scene *S, int max_depth, size_t frame_pixels,
+                         size_t owned_pixels) {
+  BounceNeeds n;
   size_t want = (size_t)S->rays_per_pixel * owned_pixels + 65536;
   if (want > 0x0ffffff0ull)
     want = 0x0ffffff0ull;
-  want = (want + rt::QUEUE_SEGMENTS - 1) / rt::QUEUE_SEGMENTS * rt::QUEUE_SEGMENTS;
-  if (B->queue_capacity < want) {
-    for (int q = 0; q < 2; q++)
-      HIP_TRY(B->queue[q].alloc(2 * want));
-    HIP_TRY(B->hit_rec.alloc(want));
-    HIP_TRY(B->hit_idx.alloc(want));
-    if (S->has_tbvh) {
-      HIP_TRY(B->tri_hit_rec.alloc(want));
-      HIP_TRY(B->tri_hit_idx.alloc(want));
-    }
-    const int per_ray = S->l_size < kLightGroup ? (S->l_size > 0 ? S->l_size : 1) : kLightGroup;
-    for (int k = 0; k < 2; k++)
-      HIP_TRY(B->shadow_items[k].alloc(2 * want * per_ray));
-    B->queue_capacity = want;
+  n.capacity = (want + rt::QUEUE_SEGMENTS - 1) / rt::QUEUE_SEGMENTS * rt::QUEUE_SEGMENTS;
+  n.per_ray = S->l_size < kLightGroup ? (S->l_size > 0 ? S->l_size : 1) : kLightGroup;
+  n.tri = S->has_tbvh;
+  n.levels = max_depth + 2; // levels 0 .. max_depth + 1 (the last spawn target)
+  n.ctl_rows = 3 + 3 * ((S->l_size + kLightGroup - 1) / kLightGroup + 1);
+  n.frame_pixels = frame_pixels;
+  return n;
+}
+
+// The scene's own arena: grown (never shrunk) to what the frame needs.
+int ensure_arena(rt_scene *S, const BounceNeeds &need) {
+  if (!S->arena.counts || !S->arena.have.covers(need)) {
+    BounceNeeds n = S->arena.have;
+    n.grow_to(need);
+    BounceArena probe;
+    const size_t bytes = probe.carve(nullptr, n);
+    HIP_TRY(hipDeviceSynchronize()); // nothing may still use the old region
+    HIP_TRY(S->arena_mem.alloc(bytes));
+    S->arena = BounceArena();
+    S->arena.carve(S->arena_mem.p, n);
+    // the per-pixel sums start at zero and k_compose leaves them at zero
+    HIP_TRY(hipMemset(S->arena.extra, 0, n.frame_pixels * sizeof(unsigned long long)));
   }
-  if (!B->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking));
+  if (!S->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) {
-      HIP_TRY(hipEventCreateWithFlags(&B->ev_fork[k], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&B->ev_join[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&S->ev_fork[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&S->ev_join[k], hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&B->ev_end, hipEventDisableTiming));
-  }
-  if (own_stream && !B->main)
-    HIP_TRY(hipStreamCreateWithFlags(&B->main, hipStreamNonBlocking));
-  if (!B->counts.p) {
-    B->ctl_rows = 3 + 3 * ((S->l_size + kLightGroup - 1) / kLightGroup + 1);
-    HIP_TRY(B->counts.alloc((size_t)kLevels * B->ctl_rows * kRowWords + 1));
-  }
-  if (S->extra_pixels < frame_pixels) {
-    HIP_TRY(S->extra.alloc(frame_pixels));
-    HIP_TRY(hipMemset(S->extra.p, 0, frame_pixels * sizeof(unsigned long long)));
-    S->extra_pixels = frame_pixels;
   }
   return RT_OK;
-}
-
-uint32_t *ctl(BounceLane *B, int level, int row) {
-  return B->counts.p + ((size_t)level * B->ctl_rows + row) * kRowWords;
-}
-uint32_t *overflow_flag(BounceLane *B) {
-  return B->counts.p + (size_t)kLevels * B->ctl_rows * kRowWords;
-}
-
-rt::RayQueue queue_for_level(BounceLane *B, int level) {
-  rt::RayQueue q;
-  q.items = B->queue[level & 1].p;
-  q.count = ctl(B, level, 0);
-  q.seg_capacity = (uint32_t)(B->queue_capacity / rt::QUEUE_SEGMENTS);
-  q.overflow = overflow_flag(B);
-  return q;
 }
 
 rt::CameraDev camera_dev(const camera *cam, int w, int h) {
@@ -431,12 +485,12 @@ int rt_device_count(void) {
   return n;
 }
 
-int rt_scene_create(const scene_desc *scene, rt_scene **out) {
+static int scene_create(const scene_desc *scene, bool need_colors, rt_scene **out) {
   if (!out)
     return fail(RT_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
   int rc;
-  if ((rc = check_scene_desc(scene)) || (rc = ensure_device()))
+  if ((rc = check_scene_desc(scene, need_colors)) || (rc = ensure_device()))
     return rc;
   rt_scene *S = new (std::nothrow) rt_scene;
   if (!S)
@@ -450,169 +504,30 @@ int rt_scene_create(const scene_desc *scene, rt_scene **out) {
   return RT_OK;
 }
 
-void rt_scene_destroy(rt_scene *scene) { delete scene; }
-
-// One sub-frame: lane `lane` of `n_lanes`.  Lane 0 runs on the caller's stream,
-// the others on their own, started after everything the caller queued before.
-static int render_lane(rt_scene *S, int lane, int n_lanes, const camera *cam, const rt_frame *fr,
-                       int band_rows, int band_count, bool bounces, hipStream_t caller,
-                       uint64_t *dev_ray_count, uint64_t *dev_verify) {
-  BounceLane *B = &S->lanes[lane];
-  const int sub_index = fr->band_index + lane * band_count;
-  const int sub_count = band_count * n_lanes;
-  rt::FrameDev f;
-  f.fb = fr->dev_fb;
-  f.ids = fr->dev_ids;
-  f.ray_count = dev_ray_count;
-  f.w = fr->w;
-  f.h = fr->h;
-  f.max_depth = fr->max_depth;
-  f.band_rows = band_rows;
-  f.band_index = sub_index;
-  f.band_count = sub_count;
-  int bands_total = (fr->h + band_rows - 1) / band_rows;
-  int owned = bands_total > sub_index ? (bands_total - sub_index + sub_count - 1) / sub_count : 0;
-  const int owned_tile_rows = owned * (band_rows / 8);
-  rt::BounceDev bd;
-  memset(&bd, 0, sizeof bd);
-  bd.max_depth = 1;
-  hipStream_t st = caller;
-  int rc;
-  if (bounces) {
-    rc = ensure_bounce_buffers(S, B, lane > 0, (size_t)fr->w * fr->h,
-                               (size_t)owned_tile_rows * 8 * fr->w);
-    if (rc)
-      return rc;
-    if (lane > 0) {
-      st = B->main;
-      HIP_TRY(hipStreamWaitEvent(st, S->ev_begin, 0));
-    }
-    // only the levels this frame can reach, and the overflow flag
-    HIP_TRY(hipMemsetAsync(B->counts.p, 0,
-                           (size_t)(fr->max_depth + 2) * B->ctl_rows * kRowWords * sizeof(uint32_t),
-                           st));
-    HIP_TRY(hipMemsetAsync(overflow_flag(B), 0, sizeof(uint32_t), st));
-    bd.max_depth = fr->max_depth;
-    bd.extra = S->extra.p;
-    bd.out = queue_for_level(B, 2);
-  }
-  const rt::SceneDev sd = S->dev();
-  // 0 plain loop, 1 automatic (hierarchy when the scene has one, else the beam
-  // screen), 2 beam screen, 3 hierarchy
-  int accel = RT_BEAM_NONE;
-  if (g_screen == 2 || ((g_screen == 1 || g_screen == 3) && !S->has_bvh))
-    accel = RT_BEAM_APEX;
-  else if (g_screen == 1 || g_screen == 3)
-    accel = RT_ACCEL_BVH;
-  HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, owned_tile_rows,
-                            accel, (unsigned long long *)dev_verify, st));
-  if (bounces) {
-    // With a sphere hierarchy each level runs as walk / shade / shadow-walk
-    // launches with dynamic ray fetch (rt_walk.h); otherwise, or in the
-    // self-checking build, as one k_bounce launch per level.
-    const bool stream_levels = (sd.bvh != nullptr || sd.tbvh != nullptr) && !dev_verify;
-    const bool tri_walks = sd.tbvh != nullptr;
-    bool joined[2] = {false, false};
-    for (int level = 2; level <= fr->max_depth; level++) {
-      bd.in = queue_for_level(B, level);
-      bd.out = queue_for_level(B, level + 1);
-      if (!stream_levels) {
-        HIP_TRY(rt::launch_bounce(sd, bd, g_screen != 0, dev_ray_count,
-                                  (unsigned long long *)dev_verify, kBounceBlocks, st));
-        continue;
-      }
-      rt::HitList hl, tl;
-      hl.rec = B->hit_rec.p;
-      hl.idx = B->hit_idx.p;
-      tl.rec = tri_walks ? B->tri_hit_rec.p : nullptr;
-      tl.idx = tri_walks ? B->tri_hit_idx.p : nullptr;
-      rt::WalkArgs wa;
-      memset(&wa, 0, sizeof wa);
-      wa.fetch_at = rt::WALK_FETCH_AT;
-      wa.in = bd.in;
-      wa.extra = S->extra.p;
-      // Each ray is counted once, by the first walk it goes through.  The sphere
-      // walk goes first: it is several times cheaper per ray (a 320 KB tree in L2, 41
-      // instructions per child against ~90), and the |P| of its hit then bounds the
-      // triangle walk (a triangle only matters at |P| <= the sphere's, renderer.cpp:181).
-      wa.cursor = ctl(B, level, 1);
-      wa.hits = hl;
-      wa.ray_count = dev_ray_count;
-      HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
-      if (tri_walks) {
-        wa.cursor = ctl(B, level, 2);
-        wa.hits = tl;
-        wa.prior = hl;
-        wa.ray_count = nullptr;
-        HIP_TRY(rt::launch_walk(sd, wa, false, true, kBounceBlocks, st));
-      }
-      rt::ShadeArgs sa;
-      memset(&sa, 0, sizeof sa);
-      sa.rays = bd.in;
-      sa.hits = hl;
-      sa.tri_hits = tl;
-      sa.max_depth = fr->max_depth;
-      sa.next = bd.out;
-      sa.ray_count = dev_ray_count;
-      const int n_groups = S->l_size > 0 ? (S->l_size + kLightGroup - 1) / kLightGroup : 1;
-      const int per_ray = S->l_size < kLightGroup ? (S->l_size > 0 ? S->l_size : 1) : kLightGroup;
-      // one group of lights: its shadow walks go to the side stream; more groups
-      // share the item buffer and stay in order on the caller's stream
-      const bool fork = n_groups == 1 && S->l_size > 0 && g_side_stream != 0;
-      const int par = level & 1;
-      for (int g = 0; g < n_groups; g++) {
-        sa.light_begin = g * kLightGroup;
-        sa.light_end = S->l_size < (g + 1) * kLightGroup ? S->l_size : (g + 1) * kLightGroup;
-        sa.spawn = g == 0;
-        sa.shadow.items = B->shadow_items[fork ? par : 0].p;
-        sa.shadow.count = ctl(B, level, 3 + 3 * g);
-        sa.shadow.seg_capacity = bd.in.seg_capacity * per_ray;
-        sa.shadow.overflow = overflow_flag(B);
-        if (fork && joined[par]) // the shadow walk two levels up has read this buffer
-          HIP_TRY(hipStreamWaitEvent(st, B->ev_join[par], 0));
-        HIP_TRY(rt::launch_shade(sd, sa, kBounceBlocks, st));
-        if (S->l_size > 0) {
-          hipStream_t ws_stream = st;
-          if (fork) {
-            HIP_TRY(hipEventRecord(B->ev_fork[par], st));
-            HIP_TRY(hipStreamWaitEvent(B->side, B->ev_fork[par], 0));
-            ws_stream = B->side;
-          }
-          rt::WalkArgs ws;
-          memset(&ws, 0, sizeof ws);
-          ws.fetch_at = rt::WALK_FETCH_AT;
-          ws.in = sa.shadow;
-          ws.extra = S->extra.p;
-          // spheres first (the cheaper walk); only what they leave unoccluded is
-          // worth a triangle walk
-          ws.cursor = ctl(B, level, 4 + 3 * g);
-          ws.ray_count = dev_ray_count;
-          ws.last_stage = tri_walks ? 0 : 1;
-          HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, ws_stream));
-          if (tri_walks) {
-            ws.cursor = ctl(B, level, 5 + 3 * g);
-            ws.ray_count = nullptr;
-            ws.last_stage = 1;
-            HIP_TRY(rt::launch_walk(sd, ws, true, true, kBounceBlocks, ws_stream));
-          }
-          if (fork) {
-            HIP_TRY(hipEventRecord(B->ev_join[par], B->side));
-            joined[par] = true;
-          }
-        }
-      }
-    }
-    for (int k = 0; k < 2; k++)
-      if (joined[k])
-        HIP_TRY(hipStreamWaitEvent(st, B->ev_join[k], 0));
-    if (lane > 0)
-      HIP_TRY(hipEventRecord(B->ev_end, st));
-  }
-  return RT_OK;
+int rt_scene_create(const scene_desc *scene, rt_scene **out) {
+  return scene_create(scene, true, out);
 }
 
-static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr,
-                              uint64_t *dev_ray_count, uint64_t *dev_verify) {
+void rt_scene_destroy(rt_scene *scene) {
+  if (!scene)
+    return;
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  (void)hipSetDevice(scene->device);
+  delete scene;
+  if (have)
+    (void)hipSetDevice(cur);
+}
+
+// What of a frame this call renders.
+struct FramePlan {
+  int band_rows = 8, band_count = 1;
+  int owned_tile_rows = 0;
+  bool bounces = false;
+  bool unlit = false;
+};
+
+static int plan_frame(const rt_scene *S, const camera *cam, const rt_frame *fr, FramePlan &P) {
   if (!S || !cam || !fr)
     return fail(RT_ERR_BAD_ARG, "scene, camera or frame is NULL");
   if (!fr->dev_fb)
@@ -621,47 +536,200 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
     return fail(RT_ERR_BAD_ARG, "frame size %dx%d", fr->w, fr->h);
   if (fr->max_depth < 1)
     return fail(RT_ERR_BAD_ARG, "max_depth %d < 1", fr->max_depth);
-  int band_count = fr->band_count < 1 ? 1 : fr->band_count;
-  int band_rows = band_count == 1 ? 8 : fr->band_rows;
-  if (band_rows <= 0 || (band_rows & 7))
-    return fail(RT_ERR_BAD_ARG, "band_rows %d must be a positive multiple of 8",
-                band_rows);
-  if (fr->band_index < 0 || fr->band_index >= band_count)
-    return fail(RT_ERR_BAD_ARG, "band_index %d outside [0,%d)", fr->band_index,
-                band_count);
+  if (fr->flags & ~RT_FRAME_UNLIT)
+    return fail(RT_ERR_BAD_ARG, "unknown frame flags 0x%x", fr->flags);
+  P.band_count = fr->band_count < 1 ? 1 : fr->band_count;
+  P.band_rows = P.band_count == 1 ? 8 : fr->band_rows;
+  if (P.band_rows <= 0 || (P.band_rows & 7))
+    return fail(RT_ERR_BAD_ARG, "band_rows %d must be a positive multiple of 8", P.band_rows);
+  if (fr->band_index < 0 || fr->band_index >= P.band_count)
+    return fail(RT_ERR_BAD_ARG, "band_index %d outside [0,%d)", fr->band_index, P.band_count);
   if (fr->max_depth > kMaxDepth)
     return fail(RT_ERR_BAD_ARG, "max_depth %d > %d", fr->max_depth, kMaxDepth);
-  if (fr->max_depth > 1 && S->l_size > 8000)
+  P.unlit = (fr->flags & RT_FRAME_UNLIT) != 0;
+  // Bounces exist only where a material asks for them.
+  P.bounces = !P.unlit && fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph);
+  if (P.bounces && S->l_size > 8000)
     return fail(RT_ERR_UNSUPPORTED, "bounces with more than 8000 lights (21-bit light sums)");
+  if (P.bounces && (size_t)fr->w * fr->h > kMaxBouncePixels)
+    return fail(RT_ERR_UNSUPPORTED,
+                "bounces on a frame of more than 2^26 pixels (a bounce ray's tag holds a "
+                "26-bit pixel index)");
+  const int bands_total = (fr->h + P.band_rows - 1) / P.band_rows;
+  const int owned = bands_total > fr->band_index
+                        ? (bands_total - fr->band_index + P.band_count - 1) / P.band_count
+                        : 0;
+  P.owned_tile_rows = owned * (P.band_rows / 8);
+  return RT_OK;
+}
+
+// Enqueues the launches of one frame on the caller's stream.  A: the bounce
+// machinery (unused without bounces); side: a stream for the shadow walks, or
+// null to keep everything on the caller's stream.
+static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, const camera *cam,
+                        const rt_frame *fr, const FramePlan &P, uint64_t *dev_ray_count,
+                        uint64_t *dev_verify) {
   hipStream_t st = (hipStream_t)fr->stream;
-  HIP_TRY(hipSetDevice(S->device));
-  int rc = scene_set_eye(S, cam, st);
+  rt::FrameDev f;
+  f.fb = fr->dev_fb;
+  f.ids = fr->dev_ids;
+  f.ray_count = dev_ray_count;
+  f.w = fr->w;
+  f.h = fr->h;
+  f.max_depth = fr->max_depth;
+  f.band_rows = P.band_rows;
+  f.band_index = fr->band_index;
+  f.band_count = P.band_count;
+  f.unlit = P.unlit ? 1 : 0;
+  rt::BounceDev bd;
+  memset(&bd, 0, sizeof bd);
+  bd.max_depth = 1;
+  if (P.bounces) {
+    // only the levels this frame can reach, and the overflow flag
+    HIP_TRY(hipMemsetAsync(A->counts, 0,
+                           (size_t)(fr->max_depth + 2) * A->have.ctl_rows * kRowWords *
+                               sizeof(uint32_t),
+                           st));
+    HIP_TRY(hipMemsetAsync(A->overflow_flag(), 0, sizeof(uint32_t), st));
+    bd.max_depth = fr->max_depth;
+    bd.extra = A->extra;
+    bd.out = A->queue_for_level(2);
+  }
+  const rt::SceneDev sd = S->dev();
+  // 0 plain loop, 1 automatic (hierarchy when the scene has one, else the beam
+  // screen), 2 beam screen, 3 hierarchy
+  int accel = RT_BEAM_NONE;
+  if (S->screen == 2 || ((S->screen == 1 || S->screen == 3) && !S->has_bvh))
+    accel = RT_BEAM_APEX;
+  else if (S->screen == 1 || S->screen == 3)
+    accel = RT_ACCEL_BVH;
+  HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, P.owned_tile_rows, accel,
+                            (unsigned long long *)dev_verify, st));
+  if (!P.bounces)
+    return RT_OK;
+  // With a hierarchy each level runs as walk / shade / shadow-walk launches with
+  // dynamic ray fetch (rt_walk.h); otherwise, or in the self-checking build, as
+  // one k_bounce launch per level.
+  const bool stream_levels = (sd.bvh != nullptr || sd.tbvh != nullptr) && !dev_verify;
+  const bool tri_walks = sd.tbvh != nullptr;
+  bool joined[2] = {false, false};
+  for (int level = 2; level <= fr->max_depth; level++) {
+    bd.in = A->queue_for_level(level);
+    bd.out = A->queue_for_level(level + 1);
+    if (!stream_levels) {
+      HIP_TRY(rt::launch_bounce(sd, bd, S->screen != 0, dev_ray_count,
+                                (unsigned long long *)dev_verify, kBounceBlocks, st));
+      continue;
+    }
+    rt::HitList hl, tl;
+    hl.rec = A->hit_rec;
+    hl.idx = A->hit_idx;
+    tl.rec = tri_walks ? A->tri_hit_rec : nullptr;
+    tl.idx = tri_walks ? A->tri_hit_idx : nullptr;
+    rt::WalkArgs wa;
+    memset(&wa, 0, sizeof wa);
+    wa.fetch_at = rt::WALK_FETCH_AT;
+    wa.in = bd.in;
+    wa.extra = A->extra;
+    // Each ray is counted once, by the first walk it goes through.  The sphere
+    // walk goes first: it is several times cheaper per ray, and the |P| of its hit
+    // then bounds the triangle walk (a triangle only matters at |P| <= the
+    // sphere's, renderer.cpp:181).
+    wa.cursor = A->ctl(level, 1);
+    wa.hits = hl;
+    wa.ray_count = dev_ray_count;
+    HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
+    if (tri_walks) {
+      wa.cursor = A->ctl(level, 2);
+      wa.hits = tl;
+      wa.prior = hl;
+      wa.ray_count = nullptr;
+      HIP_TRY(rt::launch_walk(sd, wa, false, true, kBounceBlocks, st));
+    }
+    rt::ShadeArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.rays = bd.in;
+    sa.hits = hl;
+    sa.tri_hits = tl;
+    sa.max_depth = fr->max_depth;
+    sa.next = bd.out;
+    sa.ray_count = dev_ray_count;
+    const int n_groups = S->l_size > 0 ? (S->l_size + kLightGroup - 1) / kLightGroup : 1;
+    // one group of lights: its shadow walks go to the side stream; more groups
+    // share the item buffer and stay in order on the caller's stream
+    const bool fork = n_groups == 1 && S->l_size > 0 && side != nullptr;
+    const int par = level & 1;
+    for (int g = 0; g < n_groups; g++) {
+      sa.light_begin = g * kLightGroup;
+      sa.light_end = S->l_size < (g + 1) * kLightGroup ? S->l_size : (g + 1) * kLightGroup;
+      sa.spawn = g == 0;
+      sa.shadow.items = A->shadow_items[fork ? par : 0];
+      sa.shadow.count = A->ctl(level, 3 + 3 * g);
+      sa.shadow.seg_capacity = bd.in.seg_capacity * A->have.per_ray;
+      sa.shadow.overflow = A->overflow_flag();
+      if (fork && joined[par]) // the shadow walk two levels up has read this buffer
+        HIP_TRY(hipStreamWaitEvent(st, S->ev_join[par], 0));
+      HIP_TRY(rt::launch_shade(sd, sa, kBounceBlocks, st));
+      if (S->l_size > 0) {
+        hipStream_t ws_stream = st;
+        if (fork) {
+          HIP_TRY(hipEventRecord(S->ev_fork[par], st));
+          HIP_TRY(hipStreamWaitEvent(side, S->ev_fork[par], 0));
+          ws_stream = side;
+        }
+        rt::WalkArgs ws;
+        memset(&ws, 0, sizeof ws);
+        ws.fetch_at = rt::WALK_FETCH_AT;
+        ws.in = sa.shadow;
+        ws.extra = A->extra;
+        // spheres first (the cheaper walk); only what they leave unoccluded is
+        // worth a triangle walk
+        ws.cursor = A->ctl(level, 4 + 3 * g);
+        ws.ray_count = dev_ray_count;
+        ws.last_stage = tri_walks ? 0 : 1;
+        HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, ws_stream));
+        if (tri_walks) {
+          ws.cursor = A->ctl(level, 5 + 3 * g);
+          ws.ray_count = nullptr;
+          ws.last_stage = 1;
+          HIP_TRY(rt::launch_walk(sd, ws, true, true, kBounceBlocks, ws_stream));
+        }
+        if (fork) {
+          HIP_TRY(hipEventRecord(S->ev_join[par], side));
+          joined[par] = true;
+        }
+      }
+    }
+  }
+  for (int k = 0; k < 2; k++)
+    if (joined[k])
+      HIP_TRY(hipStreamWaitEvent(st, S->ev_join[k], 0));
+  HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, (size_t)fr->w * fr->h, st));
+  return RT_OK;
+}
+
+static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr,
+                              uint64_t *dev_ray_count, uint64_t *dev_verify) {
+  FramePlan P;
+  int rc = plan_frame(S, cam, fr, P);
   if (rc)
     return rc;
-  // Bounces exist only where a material asks for them.
-  const bool bounces = fr->max_depth > 1 && (S->has_mat_tri || S->has_mat_sph);
-  int n_lanes = bounces && !dev_verify ? g_lanes : 1;
-  if (n_lanes < 1)
-    n_lanes = 1;
-  if (n_lanes > kMaxLanes)
-    n_lanes = kMaxLanes;
-  if (n_lanes > 1) {
-    if (!S->ev_begin)
-      HIP_TRY(hipEventCreateWithFlags(&S->ev_begin, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(S->ev_begin, st));
-  }
-  for (int k = 0; k < n_lanes; k++) {
-    // lane k renders bands band_index + k * band_count, stepping n_lanes * band_count
-    rc = render_lane(S, k, n_lanes, cam, fr, band_rows, band_count, bounces, st, dev_ray_count,
-                     dev_verify);
+  hipStream_t st = (hipStream_t)fr->stream;
+  HIP_TRY(hipSetDevice(S->device));
+  if (P.bounces) {
+    rc = ensure_arena(S, bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
+                                      (size_t)P.owned_tile_rows * 8 * fr->w));
     if (rc)
       return rc;
   }
-  if (bounces) {
-    for (int k = 1; k < n_lanes; k++)
-      HIP_TRY(hipStreamWaitEvent(st, S->lanes[k].ev_end, 0));
-    HIP_TRY(rt::launch_compose(fr->dev_fb, S->extra.p, (size_t)fr->w * fr->h, st));
-  }
+  if ((rc = scene_set_eye(S, cam, st)))
+    return rc;
+  rc = render_frame(S, &S->arena, S->side_stream ? S->side : nullptr, cam, fr, P, dev_ray_count,
+                    dev_verify);
+  if (rc)
+    return rc;
+  HIP_TRY(hipEventRecord(S->ev_frame, st));
+  S->frame_recorded = true;
   return RT_OK;
 }
 
@@ -682,12 +750,10 @@ int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {
     return fail(RT_ERR_BAD_ARG, "scene or result is NULL");
   *overflowed = 0;
   HIP_TRY(hipSetDevice(S->device));
-  for (int k = 0; k < kMaxLanes; k++) {
-    if (!S->lanes[k].counts.p)
-      continue;
+  if (S->arena.counts) {
     uint32_t flag = 0;
-    HIP_TRY(hipMemcpy(&flag, overflow_flag(&S->lanes[k]), sizeof flag, hipMemcpyDeviceToHost));
-    *overflowed |= flag != 0;
+    HIP_TRY(hipMemcpy(&flag, S->arena.overflow_flag(), sizeof flag, hipMemcpyDeviceToHost));
+    *overflowed = flag != 0;
   }
   return RT_OK;
 }
@@ -699,6 +765,40 @@ int rt_scene_set_rays_per_pixel(rt_scene *S, int n) {
     return fail(RT_ERR_BAD_ARG, "rays per pixel %d outside 1..256", n);
   S->rays_per_pixel = n;
   return RT_OK;
+}
+
+int rt_scene_set_screen(rt_scene *S, int mode) {
+  if (!S)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  if (mode < 0 || mode > 3)
+    return fail(RT_ERR_BAD_ARG, "screen mode %d outside 0..3", mode);
+  S->screen = mode;
+  return RT_OK;
+}
+
+int rt_scene_set_side_stream(rt_scene *S, int on) {
+  if (!S)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  S->side_stream = on != 0;
+  return RT_OK;
+}
+
+void rt_set_screen(int mode) { g_default_screen.store(mode < 0 || mode > 3 ? 1 : mode); }
+int rt_get_screen(void) { return g_default_screen.load(); }
+
+int rt_band_plan(int h, int band_rows, int band_index, int band_count, int32_t *row_begin,
+                 int32_t *row_end, int max_bands) {
+  if (h <= 0 || band_rows <= 0 || (band_rows & 7) || band_count < 1 || band_index < 0 ||
+      band_index >= band_count || max_bands < 0 || (max_bands > 0 && (!row_begin || !row_end)))
+    return fail(RT_ERR_BAD_ARG, "rt_band_plan: bad arguments");
+  const int bands_total = (h + band_rows - 1) / band_rows;
+  int n = 0;
+  for (int b = band_index; b < bands_total; b += band_count, n++)
+    if (n < max_bands) {
+      row_begin[n] = b * band_rows;
+      row_end[n] = std::min(h, (b + 1) * band_rows);
+    }
+  return n;
 }
 
 // Host-only self-check of the two hierarchy builders (no HIP call): walks each
@@ -837,77 +937,334 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
   return RT_OK;
 }
 
-void rt_set_side_stream(int on) { g_side_stream = on != 0; }
-int rt_get_side_stream(void) { return g_side_stream; }
-void rt_set_lanes(int n) { g_lanes = n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n); }
-int rt_get_lanes(void) { return g_lanes; }
-void rt_set_screen(int enabled) { g_screen = enabled; }
-int rt_get_screen(void) { return g_screen; }
+// ---- scenes kept between one-call renders -------------------------------------
+// gpu_render* receive host arrays every time.  The device copy of the last scene
+// (per device) is kept and reused when the next call brings the same pointers,
+// sizes and bytes; a 64-bit hash of all arrays decides the last point (a
+// million triangles hash in a few ms, their hierarchy takes 0.3 s to build).
+} // extern "C"
 
-int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
-                   int32_t *hit_ids, uint64_t *n_rays, int w, int h,
-                   int max_depth) {
+namespace {
+
+constexpr int kMaxCachedDevices = 16;
+
+struct SceneKey {
+  scene_desc d;
+  uint64_t hash = 0;
+  bool operator==(const SceneKey &o) const {
+    return memcmp(&d, &o.d, sizeof d) == 0 && hash == o.hash;
+  }
+};
+
+uint64_t hash_bytes(uint64_t h, const void *p, size_t n) {
+  // four interleaved multiply-xor lanes over 8-byte words, then the tail
+  const unsigned char *b = (const unsigned char *)p;
+  uint64_t l[4] = {h ^ 0x9e3779b97f4a7c15ull, h + 0xc2b2ae3d27d4eb4full, ~h, h * 0xff51afd7ed558ccdull};
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32)
+    for (int k = 0; k < 4; k++) {
+      uint64_t w;
+      memcpy(&w, b + i + 8 * k, 8);
+      l[k] = (l[k] ^ w) * 0x100000001b3ull;
+      l[k] ^= l[k] >> 29;
+    }
+  uint64_t r = (l[0] * 31 + l[1]) * 31 + (l[2] * 31 + l[3]);
+  for (; i < n; i++)
+    r = (r ^ b[i]) * 0x100000001b3ull;
+  return r ^ (uint64_t)n;
+}
+
+SceneKey scene_key(const scene_desc *s) {
+  SceneKey k;
+  memset(&k.d, 0, sizeof k.d); // padding bytes compare equal
+  k.d.tris = s->tris;
+  k.d.color_tri = s->color_tri;
+  k.d.t_size = s->t_size;
+  k.d.spheres = s->spheres;
+  k.d.radius = s->radius;
+  k.d.color_sphere = s->color_sphere;
+  k.d.s_size = s->s_size;
+  k.d.lights = s->lights;
+  k.d.l_size = s->l_size;
+  k.d.mat_tri = s->mat_tri;
+  k.d.mat_sphere = s->mat_sphere;
+  uint64_t h = 0x6a09e667f3bcc908ull;
+  h = hash_bytes(h, s->tris, sizeof(float) * 9 * (size_t)s->t_size);
+  if (s->color_tri)
+    h = hash_bytes(h, s->color_tri, 3 * (size_t)s->t_size);
+  h = hash_bytes(h, s->spheres, sizeof(float) * 3 * (size_t)s->s_size);
+  h = hash_bytes(h, s->radius, sizeof(float) * (size_t)s->s_size);
+  if (s->color_sphere)
+    h = hash_bytes(h, s->color_sphere, 3 * (size_t)s->s_size);
+  h = hash_bytes(h, s->lights, sizeof(float) * 3 * (size_t)s->l_size);
+  if (s->mat_tri)
+    h = hash_bytes(h, s->mat_tri, sizeof(rt_material) * (size_t)s->t_size);
+  if (s->mat_sphere)
+    h = hash_bytes(h, s->mat_sphere, sizeof(rt_material) * (size_t)s->s_size);
+  k.hash = h;
+  return k;
+}
+
+struct CachedScene {
+  rt_scene *scene = nullptr;
+  SceneKey key;
+  // frame buffers of the one-call entry points, grow-only
+  DevBuf<uint8_t> fb;
+  DevBuf<int32_t> ids;
+  DevBuf<uint64_t> cnt;
+  hipStream_t stream = nullptr; // gpu_render_multi: this device's stream
+};
+std::mutex g_cache_mutex;
+CachedScene g_cache[kMaxCachedDevices];
+uint64_t g_cache_builds = 0; // scenes built by cached_scene (for tests)
+
+// The resident scene for `s` on the current device, built if the kept one is a
+// different scene.  Call with g_cache_mutex held.
+int cached_scene(const scene_desc *s, const SceneKey &key, CachedScene **out,
+                 bool need_colors = true) {
+  int rc;
+  if ((rc = check_scene_desc(s, need_colors)) || (rc = ensure_device()))
+    return rc;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxCachedDevices)
+    return fail(RT_ERR_UNSUPPORTED, "device %d: only devices 0..%d keep a scene", dev,
+                kMaxCachedDevices - 1);
+  CachedScene &C = g_cache[dev];
+  const int mode = g_default_screen.load();
+  if (!C.scene || !(C.key == key)) {
+    rt_scene_destroy(C.scene);
+    C.scene = nullptr;
+    if ((rc = scene_create(s, need_colors, &C.scene)))
+      return rc;
+    C.key = key;
+    g_cache_builds++;
+  }
+  C.scene->screen = mode; // the one-call entry points follow rt_set_screen
+  *out = &C;
+  return RT_OK;
+}
+
+// One frame on the current device from the kept scene into the kept buffers
+// (launches only; the caller synchronises).
+int cached_frame(CachedScene &C, const camera *cam, bool want_ids, int w, int h, int max_depth,
+                 int flags, int band_rows, int band_index, int band_count, hipStream_t st) {
+  const size_t npx = (size_t)w * h;
+  if (C.fb.n < npx * 4)
+    HIP_TRY(C.fb.alloc(npx * 4));
+  if (want_ids && C.ids.n < npx)
+    HIP_TRY(C.ids.alloc(npx));
+  if (!C.cnt.p)
+    HIP_TRY(C.cnt.alloc(1));
+  HIP_TRY(hipMemsetAsync(C.cnt.p, 0, sizeof(uint64_t), st));
+  rt_frame fr;
+  memset(&fr, 0, sizeof fr);
+  fr.dev_fb = C.fb.p;
+  fr.dev_ids = want_ids ? C.ids.p : nullptr;
+  fr.w = w;
+  fr.h = h;
+  fr.max_depth = max_depth;
+  fr.band_rows = band_rows;
+  fr.band_index = band_index;
+  fr.band_count = band_count;
+  fr.flags = flags;
+  fr.stream = st;
+  return rt_render_device(C.scene, cam, &fr, C.cnt.p);
+}
+
+int render_cached(const scene_desc *scene, const camera *cam, uint8_t *rgb, int32_t *hit_ids,
+                  uint64_t *n_rays, int w, int h, int max_depth, int flags) {
   if (!cam || !rgb)
     return fail(RT_ERR_BAD_ARG, "camera or output buffer is NULL");
   if (w <= 0 || h <= 0)
     return fail(RT_ERR_BAD_ARG, "frame size %dx%d", w, h);
-  rt_scene *S = nullptr;
-  int rc = rt_scene_create(scene, &S);
+  int rc = check_scene_desc(scene);
   if (rc)
     return rc;
-  size_t npx = (size_t)w * h;
-  DevBuf<uint8_t> fb;
-  DevBuf<int32_t> ids;
-  DevBuf<uint64_t> cnt;
-  auto body = [&]() -> int {
-    HIP_TRY(fb.alloc(npx * 4));
-    if (hit_ids)
-      HIP_TRY(ids.alloc(npx));
-    HIP_TRY(cnt.alloc(1));
-    HIP_TRY(hipMemset(cnt.p, 0, sizeof(uint64_t)));
-    rt_frame fr;
-    memset(&fr, 0, sizeof fr);
-    fr.dev_fb = fb.p;
-    fr.dev_ids = ids.p;
-    fr.w = w;
-    fr.h = h;
-    fr.max_depth = max_depth;
-    fr.band_rows = 8;
-    fr.band_index = 0;
-    fr.band_count = 1;
-    fr.stream = nullptr;
-    // render; if a bounce queue overflowed, again with eight times the capacity
-    // (at 256 rays per pixel it cannot overflow)
-    for (;;) {
-      HIP_TRY(hipMemset(cnt.p, 0, sizeof(uint64_t)));
-      int r = rt_render_device(S, cam, &fr, cnt.p);
-      if (r)
-        return r;
-      HIP_TRY(hipStreamSynchronize(nullptr));
-      int over = 0;
-      if ((r = rt_scene_queue_overflowed(S, &over)))
-        return r;
-      if (!over)
-        break;
-      if (S->rays_per_pixel >= 256)
-        return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
-      S->rays_per_pixel = S->rays_per_pixel * 8 > 256 ? 256 : S->rays_per_pixel * 8;
-    }
-    HIP_TRY(hipMemcpy(rgb, fb.p, npx * 4, hipMemcpyDeviceToHost));
-    if (hit_ids)
-      HIP_TRY(hipMemcpy(hit_ids, ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (n_rays)
-      HIP_TRY(hipMemcpy(n_rays, cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    return RT_OK;
-  };
-  rc = body();
-  rt_scene_destroy(S);
-  return rc;
+  const SceneKey key = scene_key(scene);
+  std::lock_guard<std::mutex> lock(g_cache_mutex);
+  CachedScene *C = nullptr;
+  if ((rc = cached_scene(scene, key, &C)))
+    return rc;
+  rt_scene *S = C->scene;
+  const size_t npx = (size_t)w * h;
+  // render; if a bounce queue overflowed, again with eight times the capacity
+  // (at 256 rays per pixel it cannot overflow)
+  for (;;) {
+    if ((rc = cached_frame(*C, cam, hit_ids != nullptr, w, h, max_depth, flags, 8, 0, 1, nullptr)))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    int over = 0;
+    if ((rc = rt_scene_queue_overflowed(S, &over)))
+      return rc;
+    if (!over)
+      break;
+    if (S->rays_per_pixel >= 256)
+      return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
+    S->rays_per_pixel = S->rays_per_pixel * 8 > 256 ? 256 : S->rays_per_pixel * 8;
+  }
+  HIP_TRY(hipMemcpy(rgb, C->fb.p, npx * 4, hipMemcpyDeviceToHost));
+  if (hit_ids)
+    HIP_TRY(hipMemcpy(hit_ids, C->ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (n_rays)
+    HIP_TRY(hipMemcpy(n_rays, C->cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void rt_cache_clear(void) {
+  std::lock_guard<std::mutex> lock(g_cache_mutex);
+  int cur = 0;
+  const bool have_dev = hipGetDevice(&cur) == hipSuccess;
+  for (int d = 0; d < kMaxCachedDevices; d++) {
+    CachedScene &C = g_cache[d];
+    if (!C.scene && !C.fb.p && !C.ids.p && !C.cnt.p && !C.stream)
+      continue;
+    (void)hipSetDevice(d);
+    rt_scene_destroy(C.scene);
+    C.scene = nullptr;
+    C.fb.release();
+    C.ids.release();
+    C.cnt.release();
+    if (C.stream)
+      (void)hipStreamDestroy(C.stream);
+    C.stream = nullptr;
+  }
+  if (have_dev)
+    (void)hipSetDevice(cur);
+}
+
+// Scenes the one-call entry points have built so far (diagnostic, for tests of
+// the residency rule; not part of the documented interface).
+uint64_t rt_cache_builds(void) {
+  std::lock_guard<std::mutex> lock(g_cache_mutex);
+  return g_cache_builds;
+}
+
+int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
+                   int32_t *hit_ids, uint64_t *n_rays, int w, int h,
+                   int max_depth) {
+  return render_cached(scene, cam, rgb, hit_ids, n_rays, w, h, max_depth, 0);
 }
 
 int gpu_render(const scene_desc *scene, const camera *cam, uint8_t *rgb, int w,
                int h, int max_depth) {
-  return gpu_render_ids(scene, cam, rgb, nullptr, nullptr, w, h, max_depth);
+  return render_cached(scene, cam, rgb, nullptr, nullptr, w, h, max_depth, 0);
+}
+
+int gpu_render_unlit(const scene_desc *scene, const camera *cam, uint8_t *rgb, int w, int h) {
+  return render_cached(scene, cam, rgb, nullptr, nullptr, w, h, 1, RT_FRAME_UNLIT);
+}
+
+int gpu_render_multi(const scene_desc *scene, const camera *cam, uint8_t *rgb,
+                     int32_t *hit_ids, uint64_t *n_rays, int w, int h, int max_depth,
+                     int n_devices, int band_rows) {
+  if (!cam || !rgb)
+    return fail(RT_ERR_BAD_ARG, "camera or output buffer is NULL");
+  if (w <= 0 || h <= 0)
+    return fail(RT_ERR_BAD_ARG, "frame size %dx%d", w, h);
+  if (band_rows <= 0 || (band_rows & 7))
+    return fail(RT_ERR_BAD_ARG, "band_rows %d must be a positive multiple of 8", band_rows);
+  int rc = check_scene_desc(scene);
+  if (rc)
+    return rc;
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
+    return fail(RT_ERR_NO_DEVICE, "no HIP device");
+  if (n_devices < 1 || n_devices > visible || n_devices > kMaxCachedDevices)
+    return fail(RT_ERR_BAD_ARG, "n_devices %d outside 1..%d", n_devices,
+                std::min(visible, kMaxCachedDevices));
+  int home = 0;
+  HIP_TRY(hipGetDevice(&home));
+  const SceneKey key = scene_key(scene);
+  std::lock_guard<std::mutex> lock(g_cache_mutex);
+  const size_t npx = (size_t)w * h;
+  const int bands_total = (h + band_rows - 1) / band_rows;
+  CachedScene *C[kMaxCachedDevices] = {};
+  auto body = [&]() -> int {
+    // the scene on every device (the builds of different devices run one after
+    // the other on this thread; kept scenes cost nothing)
+    for (int d = 0; d < n_devices; d++) {
+      HIP_TRY(hipSetDevice(d));
+      int r = cached_scene(scene, key, &C[d]);
+      if (r)
+        return r;
+      if (!C[d]->stream)
+        HIP_TRY(hipStreamCreateWithFlags(&C[d]->stream, hipStreamNonBlocking));
+      if (d > 0) {
+        int can = 0;
+        HIP_TRY(hipDeviceCanAccessPeer(&can, 0, d));
+        if (can) { // device 0 reads its peers' bands directly over xGMI
+          hipError_t e = hipSetDevice(0) == hipSuccess ? hipDeviceEnablePeerAccess(d, 0)
+                                                       : hipErrorInvalidDevice;
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            return fail(RT_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", d, hipGetErrorString(e));
+          (void)hipGetLastError();
+        }
+      }
+    }
+    for (;;) {
+      // every device renders its bands on its own stream
+      for (int d = 0; d < n_devices; d++) {
+        HIP_TRY(hipSetDevice(d));
+        int r = cached_frame(*C[d], cam, hit_ids != nullptr, w, h, max_depth, 0, band_rows, d,
+                             n_devices, C[d]->stream);
+        if (r)
+          return r;
+      }
+      // the bands travel to device 0: one peer copy per band, on the owner's
+      // stream (behind its render), so the copies of different devices overlap
+      for (int d = 1; d < n_devices; d++) {
+        HIP_TRY(hipSetDevice(d));
+        for (int b = d; b < bands_total; b += n_devices) {
+          const size_t r0 = (size_t)b * band_rows;
+          const size_t r1 = std::min((size_t)h, r0 + band_rows);
+          const size_t off = r0 * w, cnt = (r1 - r0) * w;
+          HIP_TRY(hipMemcpyPeerAsync(C[0]->fb.p + 4 * off, 0, C[d]->fb.p + 4 * off, d, 4 * cnt,
+                                     C[d]->stream));
+          if (hit_ids)
+            HIP_TRY(hipMemcpyPeerAsync(C[0]->ids.p + off, 0, C[d]->ids.p + off, d,
+                                       sizeof(int32_t) * cnt, C[d]->stream));
+        }
+      }
+      bool over = false;
+      for (int d = 0; d < n_devices; d++) {
+        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipStreamSynchronize(C[d]->stream));
+        int o = 0;
+        int r = rt_scene_queue_overflowed(C[d]->scene, &o);
+        if (r)
+          return r;
+        over = over || o;
+      }
+      if (!over)
+        break;
+      if (C[0]->scene->rays_per_pixel >= 256)
+        return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
+      for (int d = 0; d < n_devices; d++)
+        C[d]->scene->rays_per_pixel = std::min(256, C[d]->scene->rays_per_pixel * 8);
+    }
+    HIP_TRY(hipSetDevice(0));
+    HIP_TRY(hipMemcpy(rgb, C[0]->fb.p, npx * 4, hipMemcpyDeviceToHost));
+    if (hit_ids)
+      HIP_TRY(hipMemcpy(hit_ids, C[0]->ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_rays) {
+      *n_rays = 0;
+      for (int d = 0; d < n_devices; d++) {
+        uint64_t v = 0;
+        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipMemcpy(&v, C[d]->cnt.p, sizeof v, hipMemcpyDeviceToHost));
+        *n_rays += v;
+      }
+    }
+    return RT_OK;
+  };
+  rc = body();
+  (void)hipSetDevice(home);
+  return rc;
 }
 
 int gpu_check_intersection(rt_scene *S, int64_t n, const float *orig,
@@ -922,26 +1279,45 @@ int gpu_check_intersection(rt_scene *S, int64_t n, const float *orig,
   if (!orig || !dir || !kind || !index || !P)
     return fail(RT_ERR_BAD_ARG, "NULL ray or result array");
   HIP_TRY(hipSetDevice(S->device));
-  DevBuf<float> d_o, d_d, d_P;
-  DevBuf<int32_t> d_k, d_i;
-  int rc;
-  if ((rc = upload(d_o, orig, (size_t)3 * n)) || (rc = upload(d_d, dir, (size_t)3 * n)))
-    return rc;
-  HIP_TRY(d_P.alloc((size_t)3 * n));
-  HIP_TRY(d_k.alloc((size_t)n));
-  HIP_TRY(d_i.alloc((size_t)n));
+  // staging kept by the scene (grow-only): origins then directions; kinds then
+  // indices
+  const size_t un = (size_t)n;
+  if (S->chk_in.n < 6 * un) {
+    HIP_TRY(S->chk_in.alloc(6 * un));
+    HIP_TRY(S->chk_P.alloc(3 * un));
+    HIP_TRY(S->chk_out.alloc(2 * un));
+  }
+  HIP_TRY(hipMemcpy(S->chk_in.p, orig, 3 * un * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S->chk_in.p + 3 * un, dir, 3 * un * sizeof(float), hipMemcpyHostToDevice));
   rt::CheckArgs a;
   a.n = (long)n;
-  a.orig = d_o.p;
-  a.dir = d_d.p;
-  a.kind = d_k.p;
-  a.index = d_i.p;
-  a.P = d_P.p;
+  a.orig = S->chk_in.p;
+  a.dir = S->chk_in.p + 3 * un;
+  a.kind = S->chk_out.p;
+  a.index = S->chk_out.p + un;
+  a.P = S->chk_P.p;
   HIP_TRY(rt::launch_check(S->dev(), a, nullptr));
-  HIP_TRY(hipMemcpy(kind, d_k.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(index, d_i.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(P, d_P.p, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(kind, a.kind, un * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(index, a.index, un * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(P, a.P, 3 * un * sizeof(float), hipMemcpyDeviceToHost));
   return RT_OK;
+}
+
+// One ray through the scene that gpu_render* would keep for these arrays
+// (renderer.hpp:21-23 as the reference's own callers use it: the same arrays,
+// one ray per call).  The first call uploads; later calls with unchanged arrays
+// only hash them and launch.
+int gpu_check_intersection_arrays(const scene_desc *scene, const float *orig, const float *dir,
+                                  int32_t *kind, int32_t *index, float *P) {
+  int rc = check_scene_desc(scene, false);
+  if (rc)
+    return rc;
+  const SceneKey key = scene_key(scene);
+  std::lock_guard<std::mutex> lock(g_cache_mutex);
+  CachedScene *C = nullptr;
+  if ((rc = cached_scene(scene, key, &C, false)))
+    return rc;
+  return gpu_check_intersection(C->scene, 1, orig, dir, kind, index, P);
 }
 
 } // extern "C"

@@ -35,6 +35,7 @@ struct FrameDev {
   int w, h;
   int max_depth;
   int band_rows, band_index, band_count;
+  int unlit; // 1: the reference's -DUNLIT=1 build (renderer.cpp:130-137)
 };
 
 // Bounce-ray queue in HBM: two float4 per ray,

@@ -387,8 +387,18 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
   const bool hit = inside && h.kind != 0;
   const size_t p = (size_t)f.w * (inside ? i : 0) + (inside ? j : 0);
 
-  n_rays += shade_hits<true, MATERIALS, BM, VERIFY>(sc, bd, hit, h, dx, dy, dz, 1.0f,
-                                                    (uint32_t)p, 1u, fb0, fb1, fb2, st);
+  if (f.unlit) {
+    // renderer.cpp:130-137: clamp<int>(0 + colour, 0, 255) is the colour itself
+    if (hit) {
+      const uchar4 col = h.kind == 1 ? sc.col_tri[h.index] : sc.col_sph[h.index];
+      fb0 = col.x;
+      fb1 = col.y;
+      fb2 = col.z;
+    }
+  } else {
+    n_rays += shade_hits<true, MATERIALS, BM, VERIFY>(sc, bd, hit, h, dx, dy, dz, 1.0f,
+                                                      (uint32_t)p, 1u, fb0, fb1, fb2, st);
+  }
 
   if (inside) {
     uchar4 o;

@@ -8,7 +8,9 @@
 // The frame size is a compile-time constant in the reference
 // (renderer.hpp:10-11) and the caller allocates 4*W*H bytes from the same
 // constants (main.cpp:91), so the shim is built for one size:
-// -DRT_CANVAS_WIDTH / -DRT_CANVAS_HEIGHT, default 2560 x 1440.
+// -DRT_CANVAS_WIDTH / -DRT_CANVAS_HEIGHT, default 2560 x 1440.  -DRT_UNLIT=1
+// builds the counterpart of the reference compiled with -DUNLIT=1
+// (renderer.cpp:78,130-137; CMakeLists.txt:36).
 //
 // render() returns void in the reference and cannot report failure
 // (renderer.cpp:7); on a GPU error the shim writes the reason to stderr and
@@ -24,6 +26,9 @@
 #endif
 #ifndef RT_CANVAS_HEIGHT
 #define RT_CANVAS_HEIGHT 1440
+#endif
+#ifndef RT_UNLIT
+#define RT_UNLIT 0
 #endif
 
 static scene_desc pack(float *tris, unsigned char *color_tri, int t_size,
@@ -53,7 +58,11 @@ void render(unsigned char *frameBuffer, int fov, float *tris,
   camera cam;
   rt_camera_default(&cam);
   cam.fov_deg = fov;
+#if RT_UNLIT // the reference's compile-time flat-colour variant (renderer.cpp:78)
+  int rc = gpu_render_unlit(&s, &cam, frameBuffer, RT_CANVAS_WIDTH, RT_CANVAS_HEIGHT);
+#else
   int rc = gpu_render(&s, &cam, frameBuffer, RT_CANVAS_WIDTH, RT_CANVAS_HEIGHT, 1);
+#endif
   if (rc != RT_OK) {
     fprintf(stderr, "render: GPU path failed (%d): %s\n", rc, rt_last_error());
     if (frameBuffer) {
@@ -68,47 +77,31 @@ void render(unsigned char *frameBuffer, int fov, float *tris,
   }
 }
 
-// One ray per call, as the reference's signature demands.  Correct, and slow by
-// construction (a scene upload and a kernel launch per ray): bulk callers use
-// gpu_check_intersection.  *index is left untouched on a miss, as in
-// renderer.cpp:179-180.
+// One ray per call, as the reference's signature demands.  The scene arrays are
+// kept resident on the GPU between calls (the library hashes them on every call
+// and uploads only what changed), so the reference's own calling pattern, one
+// check_intersection per pixel (renderer.cpp:60), costs a hash, two small copies
+// and a launch per ray; bulk callers use gpu_check_intersection.  *index is left
+// untouched on a miss, as in renderer.cpp:179-180.
 int check_intersection(float *tris, int t_size, float *spheres, float *radius,
                        int s_size, float *P, int *index, float *orig,
                        float *dir) {
+  // colours play no part in a geometric query
   scene_desc s = pack(tris, nullptr, t_size, spheres, radius, nullptr, s_size,
                       nullptr, 0);
-  // colours play no part in a geometric query; give the upload zeros to read
-  unsigned char *ct = nullptr, *cs = nullptr;
-  if (t_size > 0) {
-    ct = new unsigned char[3 * (size_t)t_size]();
-    s.color_tri = ct;
-  }
-  if (s_size > 0) {
-    cs = new unsigned char[3 * (size_t)s_size]();
-    s.color_sphere = cs;
-  }
-  rt_scene *S = nullptr;
-  int kind = 0;
-  int rc = rt_scene_create(&s, &S);
-  if (rc == RT_OK) {
-    int32_t k = 0, idx = -1;
-    float p[3] = {0, 0, 0};
-    rc = gpu_check_intersection(S, 1, orig, dir, &k, &idx, p);
-    if (rc == RT_OK) {
-      kind = k;
-      if (k != 0) {
-        P[0] = p[0];
-        P[1] = p[1];
-        P[2] = p[2];
-        *index = idx;
-      }
-    }
-    rt_scene_destroy(S);
-  }
-  delete[] ct;
-  delete[] cs;
-  if (rc != RT_OK)
+  int32_t k = 0, idx = -1;
+  float p[3] = {0, 0, 0};
+  int rc = gpu_check_intersection_arrays(&s, orig, dir, &k, &idx, p);
+  if (rc != RT_OK) {
     fprintf(stderr, "check_intersection: GPU path failed (%d): %s\n", rc,
             rt_last_error());
-  return kind;
+    return 0;
+  }
+  if (k != 0) {
+    P[0] = p[0];
+    P[1] = p[1];
+    P[2] = p[2];
+    *index = idx;
+  }
+  return k;
 }

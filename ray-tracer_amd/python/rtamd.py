@@ -53,8 +53,11 @@ class Frame(C.Structure):
         ("dev_fb", C.c_void_p), ("dev_ids", C.c_void_p),
         ("w", C.c_int32), ("h", C.c_int32), ("max_depth", C.c_int32),
         ("band_rows", C.c_int32), ("band_index", C.c_int32),
-        ("band_count", C.c_int32), ("stream", C.c_void_p),
+        ("band_count", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
     ]
+
+
+RT_FRAME_UNLIT = 1
 
 
 def default_camera(fov_deg: int = 90) -> Camera:
@@ -163,10 +166,23 @@ def lib() -> C.CDLL:
                                              C.POINTER(Frame), C.c_void_p, C.c_void_p]
     L.rt_set_screen.argtypes = [C.c_int]
     L.rt_set_screen.restype = None
-    L.rt_set_lanes.argtypes = [C.c_int]
-    L.rt_set_lanes.restype = None
-    L.rt_set_side_stream.argtypes = [C.c_int]
-    L.rt_set_side_stream.restype = None
+    L.rt_scene_set_screen.argtypes = [C.c_void_p, C.c_int]
+    L.rt_scene_set_side_stream.argtypes = [C.c_void_p, C.c_int]
+    L.rt_scene_set_rays_per_pixel.argtypes = [C.c_void_p, C.c_int]
+    L.rt_scene_queue_overflowed.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.gpu_render_unlit.argtypes = [C.POINTER(SceneDesc), C.POINTER(Camera), C.c_void_p,
+                                   C.c_int, C.c_int]
+    L.gpu_render_multi.argtypes = [C.POINTER(SceneDesc), C.POINTER(Camera), C.c_void_p,
+                                   C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int]
+    L.gpu_check_intersection_arrays.argtypes = [C.POINTER(SceneDesc), C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_band_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_int]
+    L.rt_cache_clear.argtypes = []
+    L.rt_cache_clear.restype = None
+    L.rt_cache_builds.argtypes = []
+    L.rt_cache_builds.restype = C.c_uint64
     L.gpu_check_intersection.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
@@ -181,12 +197,53 @@ def _check(code: int):
 SCREEN_MODES = {"off": 0, "auto": 1, "beam": 2, "bvh": 3}
 
 
-def set_screen(mode):
-    """rt_set_screen: "off" (plain every-ray-every-sphere loop), "auto" (default),
-    "beam" or "bvh"; True/False mean "auto"/"off"."""
+def _mode(mode) -> int:
     if isinstance(mode, bool):
         mode = "auto" if mode else "off"
-    lib().rt_set_screen(SCREEN_MODES[mode])
+    return SCREEN_MODES[mode]
+
+
+def set_screen(mode):
+    """rt_set_screen: the mode of scenes created from now on (rtamd.render creates
+    its scene inside the call): "off" (plain every-ray-every-sphere loop), "auto"
+    (default), "beam" or "bvh"; True/False mean "auto"/"off"."""
+    lib().rt_set_screen(_mode(mode))
+
+
+def render_unlit(scene: "Scene", w: int, h: int, cam: Optional[Camera] = None) -> np.ndarray:
+    """gpu_render_unlit: the reference built with -DUNLIT=1."""
+    cam = cam or default_camera()
+    fb = np.empty((h, w, 4), np.uint8)
+    d = scene.desc()
+    _check(lib().gpu_render_unlit(C.byref(d), C.byref(cam), fb.ctypes.data, w, h))
+    return fb
+
+
+def render_multi(scene: "Scene", w: int, h: int, max_depth: int = 1, n_devices: int = 1,
+                 band_rows: int = 8, cam: Optional[Camera] = None, want_ids: bool = True):
+    """gpu_render_multi: one frame on n_devices GPUs of this process."""
+    cam = cam or default_camera()
+    fb = np.empty((h, w, 4), np.uint8)
+    ids = np.empty((h, w), np.int32) if want_ids else None
+    n = C.c_uint64(0)
+    d = scene.desc()
+    _check(lib().gpu_render_multi(C.byref(d), C.byref(cam), fb.ctypes.data,
+                                  ids.ctypes.data if want_ids else None, C.byref(n),
+                                  w, h, max_depth, n_devices, band_rows))
+    return fb, ids, int(n.value)
+
+
+def band_plan(h: int, band_rows: int, band_index: int, band_count: int):
+    """rt_band_plan: list of (row_begin, row_end) of the bands a share owns."""
+    n = lib().rt_band_plan(h, band_rows, band_index, band_count, None, None, 0)
+    if n < 0:
+        raise RtError(n, lib().rt_last_error().decode())
+    b = np.zeros(max(n, 1), np.int32)
+    e = np.zeros(max(n, 1), np.int32)
+    n2 = lib().rt_band_plan(h, band_rows, band_index, band_count, b.ctypes.data,
+                            e.ctypes.data, n)
+    assert n2 == n
+    return [(int(b[k]), int(e[k])) for k in range(n)]
 
 
 def render(scene: Scene, w: int, h: int, max_depth: int = 1,
@@ -239,14 +296,22 @@ class DeviceScene:
         except Exception:
             pass
 
+    def set_screen(self, mode):
+        """rt_scene_set_screen: the work-avoidance mode of this scene's later frames."""
+        _check(lib().rt_scene_set_screen(self.handle, _mode(mode)))
+
+    def set_side_stream(self, on: bool):
+        """rt_scene_set_side_stream."""
+        _check(lib().rt_scene_set_side_stream(self.handle, int(bool(on))))
+
     def render_device(self, dev_fb: int, dev_ids: Optional[int], w: int, h: int,
                       max_depth: int = 1, cam: Optional[Camera] = None,
                       band_rows: int = 8, band_index: int = 0, band_count: int = 1,
                       stream: Optional[int] = None, dev_ray_count: Optional[int] = None,
-                      dev_selfcheck_stats: Optional[int] = None):
+                      dev_selfcheck_stats: Optional[int] = None, flags: int = 0):
         cam = cam or default_camera()
         f = Frame(dev_fb, dev_ids, w, h, max_depth, band_rows, band_index, band_count,
-                  stream)
+                  flags, stream)
         if dev_selfcheck_stats is not None:
             _check(lib().rt_render_device_selfcheck(self.handle, C.byref(cam), C.byref(f),
                                                     dev_ray_count, dev_selfcheck_stats))

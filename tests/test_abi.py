@@ -35,7 +35,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(rtamd.Material) == 16
     assert ctypes.sizeof(rtamd.Camera) == 20
     assert ctypes.sizeof(rtamd.SceneDesc) == 88
-    assert ctypes.sizeof(rtamd.Frame) == 48
+    assert ctypes.sizeof(rtamd.Frame) == 56
+    assert rtamd.Frame.stream.offset == 48 and rtamd.Frame.flags.offset == 40
 
 
 def test_camera_default_is_the_reference_camera():
@@ -45,3 +46,42 @@ def test_camera_default_is_the_reference_camera():
     assert cam.fov_deg == ref.fov_deg == 90          # main.cpp:88
     assert list(cam.origin) == list(ref.origin) == [0.0, 0.0, 1.0]  # renderer.cpp:39
     assert cam.plane_z == ref.plane_z == -1.0        # renderer.cpp:38
+
+
+def test_band_plan_covers_every_row_exactly_once():
+    """rt_band_plan (host arithmetic, no GPU): the shares of any split are a
+    partition of the rows, bands are dealt round-robin (renderer.cpp:27-28
+    parallelises rows; here bands of rows)."""
+    for h, band_rows in [(2160, 8), (1440, 16), (1081, 8), (7, 8), (100, 24)]:
+        for n in (1, 2, 3, 4, 8):
+            seen = [0] * h
+            for r in range(n):
+                plan = rtamd.band_plan(h, band_rows, r, n)
+                for k, (b, e) in enumerate(plan):
+                    assert b == (r + k * n) * band_rows and b < e <= h
+                    assert e - b == band_rows or e == h
+                    for i in range(b, e):
+                        seen[i] += 1
+            assert seen == [1] * h, (h, band_rows, n)
+    # a share beyond the last band owns nothing
+    assert rtamd.band_plan(16, 8, 5, 8) == []
+
+
+def test_band_plan_rejects_bad_arguments():
+    import pytest
+    for args in [(0, 8, 0, 1), (100, 12, 0, 1), (100, 8, 2, 2), (100, 8, -1, 2), (100, 8, 0, 0)]:
+        with pytest.raises(rtamd.RtError):
+            rtamd.band_plan(*args)
+
+
+def test_default_mode_round_trip():
+    """rt_set_screen only records the mode that scenes created later start with."""
+    L = rtamd.lib()
+    try:
+        for name, code in rtamd.SCREEN_MODES.items():
+            rtamd.set_screen(name)
+            assert L.rt_get_screen() == code
+        L.rt_set_screen(17)          # out of range: back to the default
+        assert L.rt_get_screen() == 1
+    finally:
+        rtamd.set_screen("auto")

@@ -120,28 +120,50 @@ def test_screen_off_gives_the_same_bounces(oracle):
         assert np.array_equal(fb, fo) and n == no, mode
 
 
-def test_lane_count_does_not_change_the_frame(oracle):
-    """rt_set_lanes splits a bounce frame into sub-frames of alternate row bands
-    on separate streams, rt_set_side_stream moves the shadow walks to a stream of
-    their own; pixels, ids and ray counts must not depend on either."""
+def test_side_stream_and_mode_of_a_resident_scene(oracle):
+    """rt_scene_set_side_stream moves the shadow walks to a stream of their own,
+    rt_scene_set_screen switches the work-avoidance mode of a resident scene;
+    pixels, ids and ray counts must not depend on either."""
+    import torch
     sc = material_scene(55, n_spheres=150, n_tris=6, n_lights=2)
-    fo, io, no = oracle.render(sc, 384, 216, max_depth=6)
-    try:
-        for lanes in (1, 2, 3, 4):
-            rtamd.lib().rt_set_lanes(lanes)
-            assert rtamd.lib().rt_get_lanes() == lanes
-            fb, ids, n = rtamd.render(sc, 384, 216, max_depth=6)
-            assert np.array_equal(ids, io), lanes
-            assert np.array_equal(fb, fo), lanes
-            assert n == no, lanes
-        rtamd.lib().rt_set_lanes(1)
+    w, h = 384, 216
+    fo, io, no = oracle.render(sc, w, h, max_depth=6)
+    dev = torch.device("cuda", 0)
+    fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    ids = torch.zeros(h, w, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    with rtamd.DeviceScene(sc) as ds:
         for side in (0, 1):
-            rtamd.lib().rt_set_side_stream(side)
-            fb, ids, n = rtamd.render(sc, 384, 216, max_depth=6)
-            assert np.array_equal(ids, io) and np.array_equal(fb, fo) and n == no, side
-    finally:
-        rtamd.lib().rt_set_lanes(1)
-        rtamd.lib().rt_set_side_stream(1)
+            for mode in ("auto", "off", "beam", "bvh"):
+                ds.set_side_stream(side)
+                ds.set_screen(mode)
+                fb.zero_(), ids.zero_(), cnt.zero_()
+                ds.render_device(fb.data_ptr(), ids.data_ptr(), w, h, max_depth=6,
+                                 dev_ray_count=cnt.data_ptr())
+                torch.cuda.synchronize()
+                assert not ds.queue_overflowed()
+                assert np.array_equal(ids.cpu().numpy(), io), (side, mode)
+                assert np.array_equal(fb.cpu().numpy(), fo), (side, mode)
+                assert int(cnt.item()) == no, (side, mode)
+        with pytest.raises(rtamd.RtError):
+            rtamd._check(rtamd.lib().rt_scene_set_screen(ds.handle, 9))
+
+
+def test_bounce_frames_beyond_2_pow_26_pixels_are_refused():
+    """A bounce ray carries its pixel in 26 bits of its tag: larger frames with
+    bounces must be refused, not rendered wrongly.  (The check precedes every
+    allocation and launch, so no such frame is ever allocated here.)"""
+    import torch
+    sc = material_scene(56)
+    with rtamd.DeviceScene(sc) as ds:
+        with pytest.raises(rtamd.RtError) as e:
+            ds.render_device(1 << 12, None, 16384, 4104, max_depth=2)   # 67.2 M pixels
+        assert e.value.code == rtamd.RT_ERR_UNSUPPORTED
+        # without bounces (depth 1) the same scene object renders as usual
+        fb = torch.zeros(64, 64, 4, dtype=torch.uint8, device="cuda")
+        ds.render_device(fb.data_ptr(), None, 64, 64, max_depth=1)
+        torch.cuda.synchronize()
+        assert int(fb[..., 3].min()) == 255
 
 
 def test_queue_capacity_grows_when_rays_multiply(oracle):
@@ -195,3 +217,42 @@ def test_triangle_mesh_configuration_reduced(oracle):
         assert sc.t_size == 4000
         compare(sc, 256, 144, 1, oracle)
         compare(sc, 256, 144, 4, oracle)
+
+
+def _device_frame(ds, w, h, depth, mode):
+    import torch
+    dev = torch.device("cuda", 0)
+    fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    ids = torch.zeros(h, w, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ds.set_screen(mode)
+    ds.render_device(fb.data_ptr(), ids.data_ptr(), w, h, max_depth=depth,
+                     dev_ray_count=cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert not ds.queue_overflowed()
+    return fb, ids, int(cnt.item())
+
+
+def test_10k_grid_4k_depth8_every_row_equals_the_plain_loop():
+    """The headline frame (10 000 spheres, 3840x2160, depth 8), all 2160 rows:
+    the default mode against the library's own every-ray-every-primitive loop,
+    which test_10k_grid_4k_depth8_row_sample pins to the oracle on sampled rows."""
+    import torch
+    sc = rtamd.material_grid_scene(100, 100)
+    with rtamd.DeviceScene(sc) as ds:
+        f0, i0, n0 = _device_frame(ds, 3840, 2160, 8, "off")
+        f1, i1, n1 = _device_frame(ds, 3840, 2160, 8, "auto")
+        assert n0 == n1
+        assert torch.equal(i0, i1)
+        assert torch.equal(f0, f1)
+
+
+def test_mesh_80k_720p_depth4_every_row_equals_the_plain_loop():
+    """80 000 triangles + 1 024 spheres, 1280x720, depth 4, every row: triangle
+    and sphere hierarchies against the plain loop."""
+    import torch
+    sc = rtamd.mesh_scene(200, 200, grid=32)
+    with rtamd.DeviceScene(sc) as ds:
+        f0, i0, n0 = _device_frame(ds, 1280, 720, 4, "off")
+        f1, i1, n1 = _device_frame(ds, 1280, 720, 4, "auto")
+        assert n0 == n1 and torch.equal(i0, i1) and torch.equal(f0, f1)

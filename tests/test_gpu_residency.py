@@ -1,0 +1,85 @@
+"""Scene residency of the drop-in calls.  The reference uploads its scene once
+per render() (`map(to:)`, renderer.cpp:13-21) and its harness pattern is one
+check_intersection per pixel with the same arrays (renderer.hpp:21-23): the
+one-call entry points keep the device copy of the last scene and rebuild it
+only when pointers, sizes or bytes change."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_scenes
+import rtamd
+
+pytestmark = pytest.mark.gpu
+
+
+def builds():
+    return int(rtamd.lib().rt_cache_builds())
+
+
+def test_second_render_of_the_same_arrays_builds_nothing(oracle):
+    sc = golden_scenes.mixed_scene(seed=61, n_spheres=60, n_tris=20)
+    rtamd.lib().rt_cache_clear()
+    b0 = builds()
+    fb1, ids1, n1 = rtamd.render(sc, 320, 200)
+    assert builds() == b0 + 1
+    fb2, ids2, n2 = rtamd.render(sc, 320, 200)
+    fb3 = rtamd.render_plain(sc, 200, 120)          # other size, same scene
+    assert builds() == b0 + 1
+    assert np.array_equal(fb1, fb2) and np.array_equal(ids1, ids2) and n1 == n2
+    fo, io, no = oracle.render(sc, 320, 200)
+    assert np.array_equal(fb1, fo) and np.array_equal(ids1, io) and n1 == no
+    assert np.array_equal(fb3, oracle.render(sc, 200, 120)[0])
+
+
+def test_a_changed_array_invalidates_the_kept_scene(oracle):
+    sc = golden_scenes.mixed_scene(seed=62, n_spheres=50, n_tris=10)
+    rtamd.lib().rt_cache_clear()
+    rtamd.render(sc, 256, 144)
+    b0 = builds()
+    # same pointers and sizes, one float changed in place
+    sc.spheres[11, 2] += np.float32(3.0)
+    fb, ids, n = rtamd.render(sc, 256, 144)
+    assert builds() == b0 + 1
+    fo, io, no = oracle.render(sc, 256, 144)
+    assert np.array_equal(fb, fo) and np.array_equal(ids, io) and n == no
+    # a colour byte, a light, a material
+    sc.color_sphere[0, 1] ^= 0x55
+    assert np.array_equal(rtamd.render(sc, 256, 144)[0], oracle.render(sc, 256, 144)[0])
+    sc.lights[0, 0] += np.float32(1.0)
+    assert np.array_equal(rtamd.render(sc, 256, 144)[0], oracle.render(sc, 256, 144)[0])
+    assert builds() == b0 + 3
+    sc.mat_sphere = rtamd.seeded_materials(sc.s_size)
+    f4 = rtamd.render(sc, 256, 144, max_depth=4)[0]
+    assert builds() == b0 + 4
+    assert np.array_equal(f4, oracle.render(sc, 256, 144, max_depth=4)[0])
+    rtamd.lib().rt_cache_clear()
+
+
+def test_shim_check_intersection_per_ray_keeps_the_scene(oracle):
+    """The reference's mangled check_intersection symbol, called once per ray with
+    the same arrays: one build, every answer equal to the oracle's."""
+    import os
+    shim = C.CDLL(os.path.join(rtamd.PKG_DIR, "host", "librt_shim.so"))
+    fn = getattr(shim, "_Z18check_intersectionPfiS_S_iS_PiS_S_")
+    fn.restype = C.c_int
+    sc = golden_scenes.mixed_scene(seed=63, n_spheres=80, n_tris=24)
+    o, d = golden_scenes.random_rays(300, seed=5)
+    ko, io, Po = oracle.check_intersection(sc, o, d)
+    rtamd.lib().rt_cache_clear()
+    b0 = builds()
+    vp = C.c_void_p
+    for r in range(len(o)):
+        P = np.zeros(3, np.float32)
+        idx = C.c_int(-7)
+        k = fn(vp(sc.tris.ctypes.data), sc.t_size, vp(sc.spheres.ctypes.data),
+               vp(sc.radius.ctypes.data), sc.s_size, vp(P.ctypes.data), C.byref(idx),
+               vp(o[r].ctypes.data), vp(d[r].ctypes.data))
+        assert k == ko[r]
+        if k:
+            assert idx.value == io[r] and np.array_equal(P.view(np.uint32), Po[r].view(np.uint32))
+        else:
+            assert idx.value == -7          # untouched on a miss, renderer.cpp:179-180
+    assert builds() == b0 + 1
+    rtamd.lib().rt_cache_clear()

@@ -18,12 +18,14 @@ import bench  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "10k-spheres-4k-depth8"
 sc, w, h, depth = bench.build_scene(name)
 dev = torch.device("cuda", 0)
-rtamd.lib().rt_set_side_stream(int(os.environ.get('SIDE', '0')))
+SIDE = int(os.environ.get('SIDE', '0'))
 flights = [int(x) for x in os.environ.get('FLIGHTS', '1,2,3,4').split(',')]
 for n in (1, 2, 4, 8):
     base = None
     for flight in flights:
         scenes = [rtamd.DeviceScene(sc) for _ in range(flight)]
+        for d in scenes:
+            d.set_side_stream(SIDE)
         streams = [torch.cuda.Stream(device=dev) for _ in range(flight)]
         fbs = [torch.zeros(h, w, 4, dtype=torch.uint8, device=dev) for _ in range(flight)]
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/kt_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT" -o kt -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/run.log" 2>&1 || { echo "failed"; tail -5 "$OUT/run.log"; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT" -o kt -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --side-stream 0 "$@" > "$OUT/run.log" 2>&1 || { echo "failed"; tail -5 "$OUT/run.log"; exit 1; }
 python3 - "$OUT" <<'PY'
 import sqlite3, glob, sys
 db = glob.glob(sys.argv[1] + "/*.db")[0]

@@ -2,7 +2,7 @@
 """Times what ONE rank of an N-GPU run does per frame, on one GPU and without
 any communication: the bands of rank 0 out of N (rt_frame.band_index/band_count).
 Strong scaling can be no better than frame(1) / (N * frame_share(N)).
-usage: rank_share.py [workload] [band_rows] [lanes]"""
+usage: rank_share.py [workload] [band_rows]"""
 import os
 import sys
 import time
@@ -21,9 +21,7 @@ dev = torch.device("cuda", 0)
 fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
 cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
-lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-rtamd.lib().rt_set_lanes(lanes)
-print(f"{name}, bands of {band_rows} rows, {lanes} lane(s)", flush=True)
+print(f"{name}, bands of {band_rows} rows", flush=True)
 base = None
 with rtamd.DeviceScene(sc) as ds:
     for n in ([int(os.environ['RANK_SHARE_N'])] if 'RANK_SHARE_N' in os.environ else (1, 2, 4, 8)):
