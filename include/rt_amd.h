@@ -272,6 +272,33 @@ int gpu_render_multi(const scene_desc *scene, const camera *cam, uint8_t *rgb,
 int rt_band_plan(int h, int band_rows, int band_index, int band_count,
                  int32_t *row_begin, int32_t *row_end, int max_bands);
 
+/* ---- for callers that may not allocate --------------------------------------
+ * No counterpart in the reference.  rt_render_device allocates the bounce
+ * machinery of a scene (ray queues, hit lists, counters, per-pixel sums) with
+ * hipMalloc on the first frame that needs it, and creates a side stream.  Code
+ * under HIP graph capture, tight serving loops and harnesses that forbid
+ * allocation cannot have that: this variant renders the same frame (same bytes,
+ * ids and ray count) and calls neither hipMalloc / hipFree nor any other
+ * allocating routine.  Its bounce machinery lives in a fixed array of
+ * RT_NOALLOC_SCRATCH_BYTES bytes that is part of the library's code object (one
+ * copy per GPU, held until the process ends); everything runs on frame->stream.
+ * A frame whose machinery does not fit returns RT_ERR_CAPACITY and renders
+ * nothing (rt_noalloc_scratch_needed tells in advance): with the default 4 rays
+ * per pixel, one light and max_depth 8 a 256 x 256 frame needs 52 MB; frames
+ * without bounces (max_depth 1, no materials, RT_FRAME_UNLIT) need none and
+ * are never refused.  All calls on one GPU share the array: calls that overlap
+ * in time on one GPU race, also from different scenes or streams; the caller
+ * serialises them.  rt_scene_queue_overflowed does not see this variant's
+ * frames: pass dev_overflow (device uint32, or NULL), which the frame sets to
+ * 0 or 1.                                                                     */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rt_render_device_noalloc(rt_scene *scene, const camera *cam,
+                             const rt_frame *frame, uint64_t *dev_ray_count,
+                             uint32_t *dev_overflow);
+/* Bytes of that array the frame would use (0 = no bounce machinery needed).  */
+int rt_noalloc_scratch_needed(rt_scene *scene, const rt_frame *frame,
+                              uint64_t *bytes);
+
 /* ---- misc ---------------------------------------------------------------- */
 const char *rt_last_error(void);
 int rt_device_count(void);

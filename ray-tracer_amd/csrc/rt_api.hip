@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <algorithm>
@@ -22,6 +23,12 @@
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
+
+// The bounce machinery of rt_render_device_noalloc: part of the code object, one
+// copy per GPU.  Host code never uses this name as an address; it asks the
+// runtime for the array's address on each device once (noalloc_scratch below).
+static __device__ __align__(256) unsigned char
+    scratch[RT_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -743,6 +750,89 @@ int rt_render_device_selfcheck(rt_scene *S, const camera *cam, const rt_frame *f
   if (!dev_stats)
     return fail(RT_ERR_BAD_ARG, "dev_stats is NULL");
   return render_device_impl(S, cam, fr, dev_ray_count, dev_stats);
+}
+
+// ---- the entry point that allocates nothing -----------------------------------
+static std::mutex g_scratch_mutex;
+static unsigned char *g_scratch_ptr[64]; // per device, filled on first use
+
+// Address of `scratch` on `device` (which must be the current device).
+static int noalloc_scratch(int device, unsigned char **out) {
+  if (device < 0 || device >= 64)
+    return fail(RT_ERR_UNSUPPORTED, "device %d: rt_render_device_noalloc serves devices 0..63",
+                device);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void *p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p)
+      return fail(RT_ERR_HIP, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = (unsigned char *)p;
+    if (getenv("RT_AMD_DEBUG"))
+      fprintf(stderr, "rt_amd: fixed array of device %d at %p (%zu bytes)\n", device, p,
+              (size_t)RT_NOALLOC_SCRATCH_BYTES);
+  }
+  *out = g_scratch_ptr[device];
+  return RT_OK;
+}
+
+int rt_noalloc_scratch_needed(rt_scene *S, const rt_frame *fr, uint64_t *bytes) {
+  if (!bytes)
+    return fail(RT_ERR_BAD_ARG, "bytes is NULL");
+  *bytes = 0;
+  camera cam;
+  rt_camera_default(&cam);
+  FramePlan P;
+  int rc = plan_frame(S, &cam, fr, P);
+  if (rc)
+    return rc;
+  if (P.bounces) {
+    BounceArena probe;
+    *bytes = probe.carve(nullptr, bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
+                                               (size_t)P.owned_tile_rows * 8 * fr->w));
+  }
+  return RT_OK;
+}
+
+int rt_render_device_noalloc(rt_scene *S, const camera *cam, const rt_frame *fr,
+                             uint64_t *dev_ray_count, uint32_t *dev_overflow) {
+  FramePlan P;
+  int rc = plan_frame(S, cam, fr, P);
+  if (rc)
+    return rc;
+  hipStream_t st = (hipStream_t)fr->stream;
+  HIP_TRY(hipSetDevice(S->device));
+  BounceArena A;
+  if (P.bounces) {
+    const BounceNeeds need = bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
+                                          (size_t)P.owned_tile_rows * 8 * fr->w);
+    const size_t bytes = A.carve(nullptr, need);
+    if (bytes > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+      return fail(RT_ERR_CAPACITY,
+                  "the frame's bounce machinery needs %zu bytes, the fixed array holds %zu",
+                  bytes, (size_t)RT_NOALLOC_SCRATCH_BYTES);
+    unsigned char *base = nullptr;
+    if ((rc = noalloc_scratch(S->device, &base)))
+      return rc;
+    A.carve(base, need);
+    // the array keeps the last call's contents: the per-pixel sums must start at
+    // zero (render_frame clears the control words and the overflow flag itself)
+    HIP_TRY(hipMemsetAsync(A.extra, 0, need.frame_pixels * sizeof(unsigned long long), st));
+  }
+  if ((rc = scene_set_eye(S, cam, st)))
+    return rc;
+  if ((rc = render_frame(S, &A, nullptr, cam, fr, P, dev_ray_count, nullptr)))
+    return rc;
+  if (dev_overflow) {
+    if (P.bounces)
+      HIP_TRY(hipMemcpyAsync(dev_overflow, A.overflow_flag(), sizeof(uint32_t),
+                             hipMemcpyDeviceToDevice, st));
+    else
+      HIP_TRY(hipMemsetAsync(dev_overflow, 0, sizeof(uint32_t), st));
+  }
+  HIP_TRY(hipEventRecord(S->ev_frame, st));
+  S->frame_recorded = true;
+  return RT_OK;
 }
 
 int rt_scene_queue_overflowed(rt_scene *S, int *overflowed) {

@@ -179,6 +179,10 @@ def lib() -> C.CDLL:
                                                 C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_band_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int]
+    L.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame),
+                                           C.c_void_p, C.c_void_p]
+    L.rt_noalloc_scratch_needed.argtypes = [C.c_void_p, C.POINTER(Frame),
+                                            C.POINTER(C.c_uint64)]
     L.rt_cache_clear.argtypes = []
     L.rt_cache_clear.restype = None
     L.rt_cache_builds.argtypes = []
@@ -318,6 +322,23 @@ class DeviceScene:
         else:
             _check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(f),
                                           dev_ray_count))
+
+    def render_device_noalloc(self, dev_fb: int, dev_ids: Optional[int], w: int, h: int,
+                              max_depth: int = 1, cam: Optional[Camera] = None,
+                              stream: Optional[int] = None,
+                              dev_ray_count: Optional[int] = None,
+                              dev_overflow: Optional[int] = None, flags: int = 0):
+        """rt_render_device_noalloc: the same frame from the library's fixed array."""
+        cam = cam or default_camera()
+        f = Frame(dev_fb, dev_ids, w, h, max_depth, 8, 0, 1, flags, stream)
+        _check(lib().rt_render_device_noalloc(self.handle, C.byref(cam), C.byref(f),
+                                              dev_ray_count, dev_overflow))
+
+    def noalloc_scratch_needed(self, w: int, h: int, max_depth: int) -> int:
+        f = Frame(1, None, w, h, max_depth, 8, 0, 1, 0, None)
+        n = C.c_uint64(0)
+        _check(lib().rt_noalloc_scratch_needed(self.handle, C.byref(f), C.byref(n)))
+        return int(n.value)
 
     def set_rays_per_pixel(self, n: int):
         """rt_scene_set_rays_per_pixel: bounce-queue capacity of later frames."""
