@@ -910,7 +910,7 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
       std::vector<int> seen(s->s_size, 0);
       struct Item {
         int node;
-        std::vector<std::pair<float4, float4>> boxes; // ancestors' child entries
+        std::vector<rt::BvhBox> boxes; // ancestors' child entries, as the walk decodes them
       };
       std::vector<Item> todo;
       todo.push_back(Item{0, {}});
@@ -919,12 +919,11 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
         todo.pop_back();
         const rt::BvhNode &N = H.nodes[it.node];
         for (int c = 0; c < rt::BVH_WIDTH; c++) {
-          int32_t link;
-          memcpy(&link, &N.b[c].w, 4);
+          const int32_t link = N.link[c];
           if (link == rt::BVH_EMPTY)
             continue;
           auto boxes = it.boxes;
-          boxes.push_back({N.a[c], N.b[c]});
+          boxes.push_back(rt::bvh_child_box(N, c));
           if (link >= 0) {
             todo.push_back(Item{link, boxes});
             continue;
@@ -933,8 +932,8 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
           seen[idx]++;
           const double r = std::fabs((double)s->radius[idx]);
           for (auto &bx : boxes) {
-            const double lo[3] = {bx.first.x, bx.first.y, bx.first.z};
-            const double hi[3] = {bx.first.w, bx.second.x, bx.second.y};
+            const double lo[3] = {bx.lo[0], bx.lo[1], bx.lo[2]};
+            const double hi[3] = {bx.hi[0], bx.hi[1], bx.hi[2]};
             double d2 = 0;
             for (int d = 0; d < 3; d++) {
               const double cc = s->spheres[3 * idx + d];
@@ -943,7 +942,7 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
               const double g = lo[d] > 0 ? lo[d] : (hi[d] < 0 ? -hi[d] : 0.0);
               d2 += g * g;
             }
-            if ((double)bx.second.z > std::sqrt(d2))
+            if ((double)bx.near > std::sqrt(d2))
               out[2]++; // distance bound above the true distance
           }
         }

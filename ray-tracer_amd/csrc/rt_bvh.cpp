@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 namespace rt {
@@ -61,17 +62,6 @@ struct Builder {
     return B;
   }
 
-  // distance from the world origin to the box, rounded down
-  static float near_bound(const Box &B) {
-    double s2 = 0;
-    for (int d = 0; d < 3; d++) {
-      const double g = B.lo[d] > 0 ? B.lo[d] : (B.hi[d] < 0 ? -(double)B.hi[d] : 0.0);
-      s2 += g * g;
-    }
-    const double dist = std::sqrt(s2);
-    return round_down(dist * (1.0 - 1e-6));
-  }
-
   void split(int b, int e, int &m) {
     int axis;
     (void)bound(b, e, axis);
@@ -83,23 +73,80 @@ struct Builder {
                      });
   }
 
-  static void store(BvhNode &N, int k, const Box &B, int32_t link, bool present) {
-    union {
-      int32_t i;
-      float f;
-    } bits;
-    bits.i = link;
-    if (present) {
-      N.a[k] = make_float4(B.lo[0], B.lo[1], B.lo[2], B.hi[0]);
-      N.b[k] = make_float4(B.hi[1], B.hi[2], near_bound(B), bits.f);
-    } else {
-      N.a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      N.b[k] = make_float4(0.f, 0.f, INFINITY, bits.f);
+  // distance from the world origin to a box, rounded down to a float whose low 16
+  // bits are zero
+  static uint32_t near_bits16(const float lo[3], const float hi[3]) {
+    double s2 = 0;
+    for (int d = 0; d < 3; d++) {
+      const double g = lo[d] > 0 ? lo[d] : (hi[d] < 0 ? -(double)hi[d] : 0.0);
+      s2 += g * g;
     }
+    const float f = round_down(std::sqrt(s2) * (1.0 - 1e-6));
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u >> 16; // truncation of a non-negative float rounds down
+  }
+
+  // Packs the boxes of a node's children.  The grid origin is the low corner of
+  // their union; per axis the unit is the smallest power of two with which 255
+  // steps reach the high corner; every corner is rounded outwards and then
+  // checked on the decoded value (the device's own arithmetic).  Returns false
+  // if some box cannot be represented (ranges beyond what a float exponent
+  // byte holds), in which case the scene gets no hierarchy.
+  static bool pack(BvhNode &N, const Box *B, const int32_t *link, int parts) {
+    memset(&N, 0, sizeof N);
+    for (int k = 0; k < BVH_WIDTH; k++)
+      N.link[k] = k < parts ? link[k] : BVH_EMPTY;
+    for (int d = 0; d < 3; d++) {
+      float lo = INFINITY, hi = -INFINITY;
+      for (int k = 0; k < parts; k++) {
+        lo = std::min(lo, B[k].lo[d]);
+        hi = std::max(hi, B[k].hi[d]);
+      }
+      if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi))
+        return false;
+      N.org[d] = lo;
+      int e = 0;
+      (void)std::frexp(((double)hi - (double)lo) / 255.0, &e); // extent / 255 < 2^e
+      e = std::max(e, -120);
+      for (;; e++) {
+        if (e + 127 > 254)
+          return false;
+        const float u = std::ldexp(1.0f, e);
+        bool ok = true;
+        uint32_t qlo = 0, qhi = 0;
+        for (int k = 0; k < parts && ok; k++) {
+          long ql = (long)std::floor(((double)B[k].lo[d] - lo) / u);
+          ql = std::max(0l, std::min(255l, ql));
+          while (ql > 0 && fmaf((float)ql, u, lo) > B[k].lo[d])
+            ql--;
+          long qh = (long)std::ceil(((double)B[k].hi[d] - lo) / u);
+          qh = std::max(0l, qh);
+          while (qh <= 255 && fmaf((float)qh, u, lo) < B[k].hi[d])
+            qh++;
+          ok = qh <= 255 && fmaf((float)ql, u, lo) <= B[k].lo[d];
+          qlo |= (uint32_t)ql << (8 * k);
+          qhi |= (uint32_t)(qh & 255) << (8 * k);
+        }
+        if (ok) {
+          N.exps |= (uint32_t)(e + 127) << (8 * d);
+          N.qlo[d] = qlo;
+          N.qhi[d] = qhi;
+          break;
+        }
+      }
+    }
+    for (int k = 0; k < parts; k++) {
+      const BvhBox D = bvh_child_box(N, k);
+      N.near_bits[k >> 1] |= near_bits16(D.lo, D.hi) << (16 * (k & 1));
+    }
+    return true;
   }
 
   // Returns the link for order[b, e) and its box.
-  int32_t build(int b, int e, Box &box) {
+  bool failed = false;
+  int depth_seen = 0;
+  int32_t build(int b, int e, Box &box, int depth = 1) {
     int axis;
     box = bound(b, e, axis);
     const int n = e - b;
@@ -133,10 +180,10 @@ struct Builder {
     Box cs[BVH_WIDTH];
     int32_t cl[BVH_WIDTH];
     for (int k = 0; k < BVH_WIDTH; k++)
-      cl[k] = k < parts ? build(lo[k], hi[k], cs[k]) : BVH_EMPTY;
-    BvhNode &N = out->nodes[me];
-    for (int k = 0; k < BVH_WIDTH; k++)
-      store(N, k, cs[k], cl[k], k < parts);
+      cl[k] = k < parts ? build(lo[k], hi[k], cs[k], depth + 1) : BVH_EMPTY;
+    if (!pack(out->nodes[me], cs, cl, parts))
+      failed = true;
+    depth_seen = std::max(depth_seen, depth);
     return me;
   }
 };
@@ -167,14 +214,18 @@ void bvh_build(const float *spheres, const float *radius, int n, BvhHost &out) {
   if (n == 1) {
     out.nodes.push_back(BvhNode{});
     int32_t l = B.build(0, 1, root);
-    BvhNode &N = out.nodes[0];
-    for (int k = 0; k < BVH_WIDTH; k++)
-      Builder::store(N, k, root, k == 0 ? l : BVH_EMPTY, k == 0);
+    if (!Builder::pack(out.nodes[0], &root, &l, 1))
+      B.failed = true;
+    B.depth_seen = 1;
   } else {
     int32_t l = B.build(0, n, root);
     (void)l; // == 0: the first node pushed
   }
-  out.valid = true;
+  out.depth = B.depth_seen;
+  // A walk keeps the node it visits next in a register and stacks at most three
+  // siblings per level: a deeper tree than the stack allows is not used at all
+  // (the walks would otherwise have to drop nodes).
+  out.valid = !B.failed && (BVH_WIDTH - 1) * B.depth_seen <= BVH_STACK;
 }
 
 } // namespace rt

@@ -323,7 +323,7 @@ __device__ __forceinline__ bool beam_keeps(const Beam &B, float4 g) {
 //           wave's rays share the apex (Xx,Xy,Xz) (the eye, or the light a shadow
 //           ray aims at) and are screened as a bundle; Dk is the lane's distance
 //           from its ray origin to the apex.  RT_ACCEL_BVH = no bundle: each lane
-//           walks the sphere hierarchy for its own ray (bvh_touches).
+//           walks the sphere hierarchy for its own ray (bvh_visit).
 //
 // Nearest is by |P| from the WORLD origin with strict '>' (lowest index wins in
 // a class); between classes a triangle wins ties ('<=', renderer.cpp:181).  A
@@ -346,21 +346,32 @@ struct ScreenStats { // filled only by the verification build of the kernels
 #define RT_BEAM_APEX 1
 #define RT_ACCEL_BVH 3
 
-// Can the line {o + t d} touch any sphere inside the box [lo, hi] of a child
-// (a = lo.xyz, hi.x; b = hi.yz, near, link)?  Must say yes whenever the float
-// discriminant test (maths.cpp:132-133) can pass for a member sphere (centre c,
-// radius r, entirely inside the box).  From the bound above,
+// One node visit of the sphere walk: which of the node's (up to four) children
+// can hold a sphere the line {o + t d} touches?  A child must be kept whenever
+// the float discriminant test (maths.cpp:132-133) can pass for a member sphere
+// (centre c, radius r, entirely inside the child's box [lo, hi]).  From the
+// bound above,
 //   dist(c, line) <= r sqrt(1+64u) + sqrt(64u) |o - c|,  sqrt(64u) = 2^-9,
-// and |o - c| <= S1 := sum over the axes of max(|lo - o|, |hi - o|), r <= S1 / 3,
-// so the line passes within 0.002 S1 of the box, i.e. through the box grown by
-// m = 0.0021 S1 on every side (the extra 1e-4 S1 is thousands of times the
-// rounding of the slab arithmetic below).  The slab test keeps the child unless
-// the entry parameter exceeds the exit parameter by more than 2^-20 of their
-// magnitudes (each carries <= 4u relative error).  ix, iy, iz = 1/d per axis:
-// a zero component gives +-inf, the slab then constrains nothing when o lies
-// inside it and rejects when o lies outside; NaN (0 x inf, inf - inf) answers
-// yes, except for a line exactly in a face plane of the grown box, which cannot
-// belong to a candidate (the true margin is strictly smaller).
+// and with S1 := the sum over the axes of max(|lo - o|, |hi - o|) >= |o - c| + r,
+// the line passes within 0.002 S1 of the box, i.e. through the box grown by
+// m = 0.0021 S1 on every side.  S1 is taken from the node's whole grid box
+// G = [org, org + 255 unit], which contains every child box, so it is at least
+// each child's own S1 and the allowances below only grow.
+//
+// Slab arithmetic.  A child corner is org + q unit (q = 0..255); per axis
+//     t_lo = fma(q_lo, U, A_lo),  U = unit * i,  A_lo = ((org - o) - m) * i
+//     t_hi = fma(q_hi, U, A_hi),                 A_hi = ((org - o) + m) * i
+// are the parameters at which the line crosses the grown box's faces (i = 1/d on
+// that axis).  Against exact arithmetic each carries at most 2^-20 S1 |i| of
+// rounding (four roundings of numbers no larger than 2 S1 |i|), a hundredth of
+// the extra 1e-4 S1 |i| that m allows on that axis.  The child is kept unless the
+// entry parameter exceeds the exit parameter by more than 2^-20 of their
+// magnitudes.  |i| is capped at 2^60 (sph_walk_ray): with |d| >= 2^-20 (the walks
+// are only used then) a direction component below 2^-60 moves the line by less
+// than 2^-39 S1 across any box in reach, so the cap only turns infinite slabs
+// into astronomically wide ones, rejects where the origin lies outside the slab
+// by more than m, and keeps 0 x inf out of the arithmetic.  Whatever NaN or
+// inf - inf is left (overflowing coordinates) answers "keep".
 //
 // Two more ways out, both one-sided, with mu = 0.0045 S1 > 2^-8 (|o - c| + r):
 //  - the grown box lies behind the ray origin by more than mu: its exit
@@ -369,46 +380,65 @@ struct ScreenStats { // filled only by the verification build of the kernels
 //    and |L|^2 - r^2 > mu^2, margins thousands of times their rounding:
 //    maths.cpp:138-152 computes two negative roots and reports no hit;
 //  - every point of the box is farther from the world origin than `bound`
-//    (the best |P| so far): near - mu > bound.  A reported P is within mu of the
+//    (the best |P| so far): near > bound + mu.  A reported P is within mu of the
 //    sphere it belongs to even when the roots are ill-conditioned (the
 //    discriminant carries an absolute error <= 17u (2|d||L|)^2, i.e. <= 1e-3 |L|
 //    on the roots), so such a child cannot supply a nearer hit.  Ties are kept:
 //    the comparison is strict.
-// entry_out: the parameter at which the line enters the grown box (an ordering key
-// for any-hit walks: the nearer an occluder is to the ray's origin, the sooner it
-// ends the walk).
-__device__ __forceinline__ bool bvh_touches(float4 a, float4 b, float ox, float oy, float oz,
-                                            float ix, float iy, float iz, float ida,
-                                            float bound, float &entry_out) {
-  const float ax = a.x - ox, ay = a.y - oy, az = a.z - oz;
-  const float bx = a.w - ox, by = b.x - oy, bz = b.y - oz;
-  const float S1 = fmaxf(fabsf(ax), fabsf(bx)) + fmaxf(fabsf(ay), fabsf(by)) +
-                   fmaxf(fabsf(az), fabsf(bz));
-  const float m = S1 * 0.0021f;
-  const float t0x = (ax - m) * ix, t1x = (bx + m) * ix;
-  const float t0y = (ay - m) * iy, t1y = (by + m) * iy;
-  const float t0z = (az - m) * iz, t1z = (bz + m) * iz;
-  const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-  const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-  const bool miss = (tmin - tmax) > 9.5367431640625e-07f * (fabsf(tmin) + fabsf(tmax));
-  const float mu = S1 * 0.0045f;
-  const bool behind = tmax < -(mu * ida);
-  const bool far = (b.z - mu) > bound;
-  entry_out = tmin;
-  return !miss && !behind && !far;
-}
-
-// Per-ray constants of the sphere walk: 1/d per axis and an upper bound of 1/|d|.
+// key[c]: ANY_HIT the parameter at which the line enters the grown box (the nearer
+// an occluder is to the ray's origin, the sooner it ends the walk), else the
+// child's distance bound from the world origin (visiting the nearest child first
+// tightens `bound` soonest).
 struct SphWalkRay {
   float ix, iy, iz, ida;
 };
+__device__ __forceinline__ float capped_inverse(float d) {
+  // 1/0 = inf and huge quotients become 2^60 with the sign of d
+  return copysignf(fminf(fabsf(1.0f / d), 1152921504606846976.0f), d);
+}
 __device__ __forceinline__ SphWalkRay sph_walk_ray(float dx, float dy, float dz, float a) {
   SphWalkRay r;
-  r.ix = 1.0f / dx;
-  r.iy = 1.0f / dy;
-  r.iz = 1.0f / dz;
+  r.ix = capped_inverse(dx);
+  r.iy = capped_inverse(dy);
+  r.iz = capped_inverse(dz);
   r.ida = __builtin_amdgcn_rsqf(a) * 1.001f;
   return r;
+}
+
+template <bool ANY_HIT>
+__device__ __forceinline__ void bvh_visit(const BvhNode &N, float ox, float oy, float oz,
+                                          float ix, float iy, float iz, float ida, float bound,
+                                          bool touch[BVH_WIDTH], float key[BVH_WIDTH]) {
+  const float ux = bvh_unit(N.exps, 0), uy = bvh_unit(N.exps, 1), uz = bvh_unit(N.exps, 2);
+  const float bx = N.org[0] - ox, by = N.org[1] - oy, bz = N.org[2] - oz;
+  const float gx = fmaf(255.0f, ux, bx), gy = fmaf(255.0f, uy, by), gz = fmaf(255.0f, uz, bz);
+  const float S1 = fmaxf(fabsf(bx), fabsf(gx)) + fmaxf(fabsf(by), fabsf(gy)) +
+                   fmaxf(fabsf(bz), fabsf(gz));
+  const float m = S1 * 0.0021f, mu = S1 * 0.0045f;
+  const float Ux = ux * ix, Uy = uy * iy, Uz = uz * iz;
+  const float Alx = (bx - m) * ix, Ahx = (bx + m) * ix;
+  const float Aly = (by - m) * iy, Ahy = (by + m) * iy;
+  const float Alz = (bz - m) * iz, Ahz = (bz + m) * iz;
+  const float behind_below = -(mu * ida);
+  const float far_above = bound + mu;
+#pragma unroll
+  for (int c = 0; c < BVH_WIDTH; c++) {
+    const int sh = 8 * c;
+    const float tlx = fmaf((float)((N.qlo[0] >> sh) & 0xffu), Ux, Alx);
+    const float tly = fmaf((float)((N.qlo[1] >> sh) & 0xffu), Uy, Aly);
+    const float tlz = fmaf((float)((N.qlo[2] >> sh) & 0xffu), Uz, Alz);
+    const float thx = fmaf((float)((N.qhi[0] >> sh) & 0xffu), Ux, Ahx);
+    const float thy = fmaf((float)((N.qhi[1] >> sh) & 0xffu), Uy, Ahy);
+    const float thz = fmaf((float)((N.qhi[2] >> sh) & 0xffu), Uz, Ahz);
+    const float tmin = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fminf(tlz, thz));
+    const float tmax = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
+    const bool miss = (tmin - tmax) > 9.5367431640625e-07f * (fabsf(tmin) + fabsf(tmax));
+    const bool behind = tmax < behind_below;
+    const float near = bvh_near(N.near_bits, c);
+    const bool far = near > far_above;
+    touch[c] = N.link[c] != BVH_EMPTY && !miss && !behind && !far;
+    key[c] = ANY_HIT ? tmin : near;
+  }
 }
 
 // ---- the triangle hierarchy (rt_tribvh.h) ------------------------------------------
@@ -747,17 +777,18 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
           n_nodes += BVH_WIDTH;
           int next = -1;
           float next_near = RT_INF;
+          bool touch[BVH_WIDTH];
+          float keys[BVH_WIDTH];
+          bvh_visit<false>(N, ox, oy, oz, wr.ix, wr.iy, wr.iz, wr.ida, bound, touch, keys);
 #pragma unroll
           for (int c = 0; c < BVH_WIDTH; c++) {
-            const int32_t link = __float_as_int(N.b[c].w);
-            float entry;
-            if (link == BVH_EMPTY || !bvh_touches(N.a[c], N.b[c], ox, oy, oz, wr.ix, wr.iy, wr.iz,
-                                                  wr.ida, bound, entry))
+            const int32_t link = N.link[c];
+            if (!touch[c])
               continue;
             if (link >= 0) {
               // keep the child nearest to the world origin for the next visit (it
               // tightens `bound`), stack the others
-              const float key = N.b[c].z;
+              const float key = keys[c];
               int push = link;
               if (key < next_near) {
                 push = next;

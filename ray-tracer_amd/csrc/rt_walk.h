@@ -297,13 +297,10 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
       } else {
         const BvhNode N = sc.bvh[node];
 #pragma unroll
-        for (int c = 0; c < BVH_WIDTH; c++) {
-          links[c] = __float_as_int(N.b[c].w);
-          float entry = 0.f;
-          touch[c] = links[c] != BVH_EMPTY &&
-                     bvh_touches(N.a[c], N.b[c], ox, oy, oz, ix, iy, iz, da, bound, entry);
-          nears[c] = ANY_HIT ? entry : N.b[c].z; // any hit: first entered, first visited
-        }
+        for (int c = 0; c < BVH_WIDTH; c++)
+          links[c] = N.link[c];
+        // any hit: first entered, first visited; nearest: nearest to the world origin first
+        bvh_visit<ANY_HIT>(N, ox, oy, oz, ix, iy, iz, da, bound, touch, nears);
       }
 #pragma unroll
       for (int c = 0; c < BVH_WIDTH; c++) {
