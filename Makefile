@@ -45,6 +45,12 @@ $(LIB): $(SRCS) $(HDRS)
 oracle:
 	$(MAKE) -C oracle
 
+# diagnostic build with cycle stamps inside the walk kernel (tools/walk_stamps.py);
+# never loaded by the product path
+stamps: $(SRCS) $(HDRS)
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DRT_STAMPS -shared -o build/librt_amd_stamps.so $(SRCS)
+
 isa: $(SRCS) $(HDRS)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/rt_kernels.s $(CSRC)/rt_kernels.hip \
@@ -55,4 +61,4 @@ clean:
 	rm -rf build
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle isa clean
+.PHONY: all lib oracle isa stamps clean

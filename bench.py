@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames rendered concurrently, each on its own stream with its own "
                          "resident scene copy (1 = strictly one frame at a time)")
+    ap.add_argument("--one-launch", type=int, default=1, choices=[0, 1],
+                    help="bounce levels in one launch (default) or a launch per stage and level")
     ap.add_argument("--side-stream", type=int, default=None, choices=[0, 1],
                     help="shadow walks of a level on a side stream (default: on with one frame "
                          "in flight, off with several)")
@@ -163,6 +165,7 @@ def main():
         sl = Slot()
         sl.scene = rtamd.DeviceScene(sc)
         sl.scene.set_side_stream(side)
+        sl.scene.set_one_launch(args.one_launch)
         sl.stream = torch.cuda.Stream(device=dev)
         sl.fb = plan.alloc_frame(dev)
         sl.send, sl.recv = plan.alloc_gather(comm_dev)

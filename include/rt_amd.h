@@ -208,6 +208,16 @@ int rt_scene_set_screen(rt_scene *scene, int mode);
  * depend on it.  No counterpart in the reference.                              */
 int rt_scene_set_side_stream(rt_scene *scene, int on);
 
+/* Bounce levels (max_depth > 1) run in one of two ways.  One launch for all
+ * levels (default, on): every wave keeps the rays its rays spawn on a stack of
+ * its own, so a frame is three launches whatever its depth.  One launch per stage
+ * and level (off): walk / shade / shadow walk with the whole frame's rays queued
+ * in HBM between them.  Scenes with a triangle hierarchy (16 or more triangles),
+ * without a sphere hierarchy, with more than four lights or with 256 rays per
+ * pixel always take the second way.  Results do not depend on it.  No
+ * counterpart in the reference.                                                */
+int rt_scene_set_one_launch(rt_scene *scene, int on);
+
 /* As rt_render_device, with a slow self-checking build of the kernel that
  * re-tests every sphere the screen dropped.  dev_stats (device, 16 x uint64,
  * zeroed by the caller) receives

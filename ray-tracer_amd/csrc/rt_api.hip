@@ -89,12 +89,26 @@ struct BounceNeeds {
   int levels = 0;          // control rows for levels 0 .. levels-1
   int ctl_rows = 0;        // control rows per level
   size_t frame_pixels = 0; // per-pixel sums for the whole frame
+  // One launch for all levels (rt_trace.h) instead of three per level: only the
+  // first-bounce queue is frame-wide, the rest is per wave.
+  bool trace = false;
+  size_t trace_waves = 0;  // waves of the k_trace grid
+  uint32_t stack_cap = 0;  // work items per wave
 
   bool covers(const BounceNeeds &o) const {
-    return capacity >= o.capacity && per_ray >= o.per_ray && (tri || !o.tri) &&
+    return trace == o.trace && trace_waves >= o.trace_waves && stack_cap >= o.stack_cap &&
+           capacity >= o.capacity && per_ray >= o.per_ray && (tri || !o.tri) &&
            levels >= o.levels && ctl_rows >= o.ctl_rows && frame_pixels >= o.frame_pixels;
   }
   void grow_to(const BounceNeeds &o) {
+    if (trace != o.trace) { // the other kind of machinery: only the pixel sums carry over
+      const size_t px = std::max(frame_pixels, o.frame_pixels);
+      *this = o;
+      frame_pixels = px;
+      return;
+    }
+    trace_waves = std::max(trace_waves, o.trace_waves);
+    stack_cap = std::max(stack_cap, o.stack_cap);
     capacity = std::max(capacity, o.capacity);
     per_ray = std::max(per_ray, o.per_ray);
     tri = tri || o.tri;
@@ -116,6 +130,7 @@ struct BounceArena {
   float4 *shadow_items[2] = {nullptr, nullptr}; // by level parity
   int32_t *hit_idx = nullptr, *tri_hit_idx = nullptr;
   unsigned long long *extra = nullptr; // per pixel, 3 x 21 bits
+  float4 *wave_stack = nullptr, *wave_hits = nullptr, *wave_save = nullptr; // k_trace
   size_t bytes = 0;
 
   // Places the regions for `n` behind `base` (256-byte aligned pieces) and
@@ -128,14 +143,18 @@ struct BounceArena {
       return p;
     };
     const size_t cap = n.capacity;
+    const size_t lvl = n.trace ? 0 : cap; // what only the launch-per-level path needs
     queue[0] = (float4 *)take(2 * cap * sizeof(float4));
-    queue[1] = (float4 *)take(2 * cap * sizeof(float4));
-    hit_rec = (float4 *)take(cap * sizeof(float4));
-    hit_idx = (int32_t *)take(cap * sizeof(int32_t));
-    tri_hit_rec = (float4 *)take(n.tri ? cap * sizeof(float4) : 0);
-    tri_hit_idx = (int32_t *)take(n.tri ? cap * sizeof(int32_t) : 0);
+    queue[1] = (float4 *)take(2 * lvl * sizeof(float4));
+    hit_rec = (float4 *)take(lvl * sizeof(float4));
+    hit_idx = (int32_t *)take(lvl * sizeof(int32_t));
+    tri_hit_rec = (float4 *)take(n.tri ? lvl * sizeof(float4) : 0);
+    tri_hit_idx = (int32_t *)take(n.tri ? lvl * sizeof(int32_t) : 0);
     for (int k = 0; k < 2; k++)
-      shadow_items[k] = (float4 *)take(2 * cap * (size_t)n.per_ray * sizeof(float4));
+      shadow_items[k] = (float4 *)take(2 * lvl * (size_t)n.per_ray * sizeof(float4));
+    wave_stack = (float4 *)take(n.trace_waves * n.stack_cap * 2 * sizeof(float4));
+    wave_hits = (float4 *)take(n.trace_waves * rt::TRACE_HIT_CAP * 3 * sizeof(float4));
+    wave_save = (float4 *)take(n.trace_waves * 64 * rt::TRACE_SAVE_WORDS * sizeof(float));
     counts = (uint32_t *)take(((size_t)n.levels * n.ctl_rows * kRowWords + 1) * sizeof(uint32_t));
     extra = (unsigned long long *)take(n.frame_pixels * sizeof(unsigned long long));
     if (base) {
@@ -179,6 +198,8 @@ struct rt_scene {
   bool has_mat_tri = false, has_mat_sph = false;
   int screen = 1;      // rt_scene_set_screen
   int side_stream = 1; // rt_scene_set_side_stream
+  int one_launch = 1;  // rt_scene_set_one_launch
+  int trace_blocks = 1024; // resident blocks of k_trace on this device
   // Eye-relative records (k_prep_eye) are rebuilt only when the eye moves.  The
   // rebuild runs on the stream of the frame that asks for it; ev_eye lets frames
   // on other streams wait for it, ev_frame marks the end of the last frame's
@@ -384,6 +405,7 @@ int scene_build(rt_scene *S, const scene_desc *s) {
   HIP_TRY(hipStreamSynchronize(nullptr)); // staging buffers die here
   S->eye_valid = false;
   S->screen = g_default_screen.load();
+  S->trace_blocks = rt::trace_resident_blocks();
   HIP_TRY(hipEventCreateWithFlags(&S->ev_eye, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&S->ev_frame, hipEventDisableTiming));
   return RT_OK;
@@ -416,10 +438,47 @@ int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
   return RT_OK;
 }
 
-// What a frame's bounce levels need (see BounceNeeds).
+// Does a frame of this scene run its bounce levels as one launch (rt_trace.h)?
+// That kernel walks the sphere hierarchy and loops over the triangles; scenes
+// with a triangle hierarchy, scenes without any hierarchy, more lights than one
+// group, and the largest queue setting (which must not be able to overflow) take
+// the launch-per-level path.
+bool uses_trace(const rt_scene *S) {
+  return S->has_bvh && S->screen != 0 && !S->has_tbvh && S->l_size <= kLightGroup &&
+         S->rays_per_pixel < 256 && S->one_launch;
+}
+
+// What a frame's bounce levels need (see BounceNeeds).  max_bytes > 0: a fixed
+// region; the grid of the one-launch kernel is cut down until it fits.
 BounceNeeds bounce_needs(const rt_scene *S, int max_depth, size_t frame_pixels,
-                         size_t owned_pixels) {
+                         size_t owned_pixels, size_t max_bytes = 0) {
   BounceNeeds n;
+  if (uses_trace(S)) {
+    // a primary hit spawns at most two rays (mirror and refracted)
+    const size_t want = 2 * owned_pixels + 65536;
+    n.trace = true;
+    n.capacity = (want + rt::QUEUE_SEGMENTS - 1) / rt::QUEUE_SEGMENTS * rt::QUEUE_SEGMENTS;
+    n.levels = 3; // only level 2 is queued
+    n.ctl_rows = 2;
+    n.frame_pixels = frame_pixels;
+    // a lane's item leaves at most 2 + lights items behind, and a wave works
+    // depth-first: 64 x (2 + lights) items per level is what a stack holds at worst
+    // when every batch is of one level; batches mix levels, hence the margin and
+    // the overflow flag
+    const int lights = S->l_size > 0 ? S->l_size : 1;
+    n.stack_cap = (uint32_t)(64 * (2 + lights) * (max_depth + 2) *
+                             std::max(1, S->rays_per_pixel / 4));
+    int blocks = S->trace_blocks;
+    n.trace_waves = (size_t)blocks * 4;
+    if (max_bytes) {
+      BounceArena probe;
+      while (blocks > 64 && probe.carve(nullptr, n) > max_bytes) {
+        blocks -= 64;
+        n.trace_waves = (size_t)blocks * 4;
+      }
+    }
+    return n;
+  }
   size_t want = (size_t)S->rays_per_pixel * owned_pixels + 65536;
   if (want > 0x0ffffff0ull)
     want = 0x0ffffff0ull;
@@ -593,9 +652,9 @@ static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, con
   bd.max_depth = 1;
   if (P.bounces) {
     // only the levels this frame can reach, and the overflow flag
+    const int used_levels = A->have.trace ? 3 : fr->max_depth + 2;
     HIP_TRY(hipMemsetAsync(A->counts, 0,
-                           (size_t)(fr->max_depth + 2) * A->have.ctl_rows * kRowWords *
-                               sizeof(uint32_t),
+                           (size_t)used_levels * A->have.ctl_rows * kRowWords * sizeof(uint32_t),
                            st));
     HIP_TRY(hipMemsetAsync(A->overflow_flag(), 0, sizeof(uint32_t), st));
     bd.max_depth = fr->max_depth;
@@ -619,6 +678,26 @@ static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, con
   // one k_bounce launch per level.
   const bool stream_levels = (sd.bvh != nullptr || sd.tbvh != nullptr) && !dev_verify;
   const bool tri_walks = sd.tbvh != nullptr;
+  if (A->have.trace && !dev_verify) {
+    // every level in one launch: the waves keep what their rays spawn (rt_trace.h)
+    rt::TraceArgs ta;
+    memset(&ta, 0, sizeof ta);
+    ta.in = A->queue_for_level(2);
+    ta.cursor = A->ctl(2, 1);
+    ta.stack = A->wave_stack;
+    ta.hits = A->wave_hits;
+    ta.save = A->wave_save;
+    ta.stack_cap = A->have.stack_cap;
+    ta.hit_cap = rt::TRACE_HIT_CAP;
+    ta.extra = A->extra;
+    ta.ray_count = dev_ray_count;
+    ta.overflow = A->overflow_flag();
+    ta.max_depth = fr->max_depth;
+    ta.fetch_at = rt::WALK_FETCH_AT;
+    HIP_TRY(rt::launch_trace(sd, ta, (int)(A->have.trace_waves / 4), st));
+    HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, (size_t)fr->w * fr->h, st));
+    return RT_OK;
+  }
   bool joined[2] = {false, false};
   for (int level = 2; level <= fr->max_depth; level++) {
     bd.in = A->queue_for_level(level);
@@ -724,9 +803,13 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
   hipStream_t st = (hipStream_t)fr->stream;
   HIP_TRY(hipSetDevice(S->device));
   if (P.bounces) {
-    rc = ensure_arena(S, bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
-                                      (size_t)P.owned_tile_rows * 8 * fr->w));
-    if (rc)
+    const int one_launch = S->one_launch;
+    if (dev_verify)
+      S->one_launch = 0; // the self-checking kernels exist for the launch-per-level path
+    const BounceNeeds need = bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
+                                          (size_t)P.owned_tile_rows * 8 * fr->w);
+    S->one_launch = one_launch;
+    if ((rc = ensure_arena(S, need)))
       return rc;
   }
   if ((rc = scene_set_eye(S, cam, st)))
@@ -789,7 +872,8 @@ int rt_noalloc_scratch_needed(rt_scene *S, const rt_frame *fr, uint64_t *bytes) 
   if (P.bounces) {
     BounceArena probe;
     *bytes = probe.carve(nullptr, bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
-                                               (size_t)P.owned_tile_rows * 8 * fr->w));
+                                               (size_t)P.owned_tile_rows * 8 * fr->w,
+                                               RT_NOALLOC_SCRATCH_BYTES));
   }
   return RT_OK;
 }
@@ -804,8 +888,9 @@ int rt_render_device_noalloc(rt_scene *S, const camera *cam, const rt_frame *fr,
   HIP_TRY(hipSetDevice(S->device));
   BounceArena A;
   if (P.bounces) {
-    const BounceNeeds need = bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
-                                          (size_t)P.owned_tile_rows * 8 * fr->w);
+    const BounceNeeds need =
+        bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
+                     (size_t)P.owned_tile_rows * 8 * fr->w, RT_NOALLOC_SCRATCH_BYTES);
     const size_t bytes = A.carve(nullptr, need);
     if (bytes > (size_t)RT_NOALLOC_SCRATCH_BYTES)
       return fail(RT_ERR_CAPACITY,
@@ -863,6 +948,13 @@ int rt_scene_set_screen(rt_scene *S, int mode) {
   if (mode < 0 || mode > 3)
     return fail(RT_ERR_BAD_ARG, "screen mode %d outside 0..3", mode);
   S->screen = mode;
+  return RT_OK;
+}
+
+int rt_scene_set_one_launch(rt_scene *S, int on) {
+  if (!S)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  S->one_launch = on != 0;
   return RT_OK;
 }
 

@@ -85,6 +85,23 @@ struct WalkArgs {
   int fetch_at;       // refill a wave when this many of its lanes have nothing to do
 };
 
+// All bounce levels in one launch (rt_trace.h).
+struct TraceArgs {
+  RayQueue in;        // first-bounce rays of the frame (written by k_render)
+  uint32_t *cursor;   // cursor[s * CTL_WORDS]: next item of segment s to hand out
+  float4 *stack;      // per wave: stack_cap work items of two float4
+  float4 *hits;       // per wave: hit_cap hit records of three float4
+  float4 *save;       // per wave: 64 lanes x TRACE_SAVE_WORDS words of walk state
+  uint32_t stack_cap, hit_cap;
+  unsigned long long *extra; // per-pixel integer light sums
+  uint64_t *ray_count;
+  uint32_t *overflow; // set to 1 when a wave's stack was too small
+  int max_depth;
+  int fetch_at;       // refill a wave when this many of its lanes have nothing to do
+};
+constexpr uint32_t TRACE_SAVE_WORDS = 20;
+constexpr uint32_t TRACE_HIT_CAP = 128; // < 64 waiting + <= 64 handed in at once
+
 struct ShadeArgs {
   RayQueue rays;     // the level's rays
   HitList hits;      // their nearest sphere hits (k_walk)
@@ -125,6 +142,10 @@ hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
                          int blocks, hipStream_t st);
 hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, bool triangles,
                        int blocks, hipStream_t st);
+hipError_t launch_trace(const SceneDev &sc, const TraceArgs &t, int blocks, hipStream_t st);
+// Blocks of k_trace that can be resident at once on the current device (what a
+// launch should use: a block that waits for a free slot finds nothing left to do).
+int trace_resident_blocks();
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st);
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st);

@@ -484,7 +484,7 @@ __global__ void k_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixel
 }
 
 } // namespace rt
-#include "rt_walk.h"
+#include "rt_trace.h"
 namespace rt {
 
 // ---------------------------------------------------------------------------
@@ -601,10 +601,37 @@ hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, bool
   return hipGetLastError();
 }
 
+hipError_t launch_trace(const SceneDev &sc, const TraceArgs &t, int blocks, hipStream_t st) {
+  if (sc.bvh == nullptr || sc.tbvh != nullptr || blocks <= 0)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_trace, dim3(blocks), dim3(256), 0, st, sc, t);
+  return hipGetLastError();
+}
+
+int trace_resident_blocks() {
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace, 256, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      per_cu <= 0 || cus <= 0)
+    return 1024;
+  return per_cu * cus;
+}
+
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, st, sc, s);
   return hipGetLastError();
 }
+
+#ifdef RT_STAMPS
+// Diagnostic build only: reads and clears the stamp counters of rt_walk.h.
+extern "C" int rt_debug_stamps(unsigned long long *out16) {
+  unsigned long long zero[16] = {};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof zero) != hipSuccess)
+    return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st) {

@@ -1,0 +1,442 @@
+// rt_trace.h — all bounce levels of a frame in ONE launch.
+//
+// k_walk / k_shade (rt_walk.h) run a bounce level as three launches with the
+// rays of the whole frame queued in HBM between them: 21 dependent launches for
+// a depth-8 frame, each ending with the few longest walks of its level while the
+// rest of the chip idles, and 6 GB of queue traffic.  Here a wave keeps what its
+// rays spawn to itself.  Every wave owns a small stack of work items in device
+// memory; it takes first-bounce rays from the frame's queue (written by
+// k_render), and everything those rays lead to - shadow rays, mirror and
+// refracted rays, down to the last level - is pushed on and popped off its own
+// stack.  Nothing is handed from one wave to another inside the launch, so no
+// level ever waits for the slowest ray of the frame, and the items stay in L2.
+//
+// Per lane the work is the walk of k_walk (same arithmetic, same order-free
+// nearest-hit rule, same parked leaves); a lane that finishes takes the next
+// item.  Rays that found their nearest sphere are appended to a per-wave list of
+// hits, and whenever 64 of them are waiting the whole wave shades them together
+// (dense lanes, like k_shade): the triangles (renderer.cpp:156-166; this kernel
+// is used for scenes whose triangles are looped over), the choice between
+// triangle and sphere (renderer.cpp:179-192), Phong per light with the shadow
+// ray's triangle test, then shadow items and the next level's rays go on the
+// stack.  Lanes that are in the middle of a walk at that moment put their walk
+// state (20 words) into a save area of the wave and take it back afterwards, so
+// the walk's registers are free while the wave shades and the kernel's register
+// budget is the larger of the two phases, not their sum.
+//
+// Results cannot depend on any of this scheduling: the nearest-hit rule is order
+// independent and bounce light is a commutative integer sum (rt_kernels.hip).
+#pragma once
+#include "rt_walk.h"
+
+namespace rt {
+
+// One work item = two float4, as in the frame's queue:
+//   ray    : (origin.xyz, weight > 0)              (dir.xyz, bits of pixel << 6 | depth)
+//   shadow : (origin.xyz, bits of pixel | 2^31)    (dir.xyz, bits of the packed light)
+// The sign bit of the fourth word tells them apart (a weight is positive, a pixel
+// index is below 2^26).
+#define RT_ITEM_SHADOW 0x80000000u
+
+// The wave's stack of items: push for the lanes with `want`, consecutive slots in
+// lane order.  Returns the new height.  An item that does not fit is dropped
+// and `overflow` is set (the host then renders the frame again another way).
+__device__ __forceinline__ uint32_t stack_push(float4 *stack, uint32_t sp, uint32_t cap,
+                                               uint32_t *overflow, bool want, float4 a,
+                                               float4 b) {
+  const unsigned long long m = __ballot(want);
+  if (!m)
+    return sp;
+  const int lane = threadIdx.x & 63;
+  const uint32_t slot = sp + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+  if (want) {
+    if (slot < cap) {
+      stack[2 * (size_t)slot] = a;
+      stack[2 * (size_t)slot + 1] = b;
+    } else {
+      *overflow = 1u;
+    }
+  }
+  const uint32_t top = sp + (uint32_t)__builtin_popcountll(m);
+  return top < cap ? top : cap;
+}
+
+struct ShadeResult {
+  uint32_t sp;     // stack height after the pushes
+  uint32_t n_rays; // shadow rays this lane finished here (blocked by a triangle)
+};
+
+// Shades n (<= 64) hit records, one per lane: records hits[3 * (first + lane)].
+// A record is the ray's item followed by (P.xyz, bits of the sphere index or -1).
+__device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *stack,
+                                                   uint32_t sp, uint32_t cap,
+                                                   uint32_t *overflow, const float4 *hits,
+                                                   uint32_t first, uint32_t n, int max_depth) {
+  const uint32_t lane = threadIdx.x & 63;
+  const bool live = lane < n;
+  ShadeResult out;
+  out.n_rays = 0;
+  Hit h;
+  h.kind = 0;
+  h.index = -1;
+  h.Px = h.Py = h.Pz = 0;
+  float dx = 0, dy = 0, dz = 0, wgt = 0;
+  uint32_t pixel = 0, depth = 0;
+  if (live) {
+    const float4 *rec = hits + 3 * (size_t)(first + lane);
+    const float4 qa = rec[0], qb = rec[1], sh = rec[2];
+    const float ox = qa.x, oy = qa.y, oz = qa.z;
+    wgt = qa.w;
+    dx = qb.x;
+    dy = qb.y;
+    dz = qb.z;
+    const uint32_t tag = __float_as_uint(qb.w);
+    pixel = tag >> 6;
+    depth = tag & 63u;
+    const int idx_s = __float_as_int(sh.w);
+    // |P| as the walk computed it: the same three products and sums (maths.cpp:23-25)
+    const float len_s = idx_s >= 0 ? length3(sh.x, sh.y, sh.z) : RT_INF;
+    float len_t = RT_INF, tPx = 0, tPy = 0, tPz = 0;
+    int idx_t = -1;
+    lane_triangles(sc, false, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
+    if (idx_t >= 0 || idx_s >= 0) { // renderer.cpp:179-192
+      if (len_t <= len_s) {
+        h.kind = 1;
+        h.index = idx_t;
+        h.Px = tPx;
+        h.Py = tPy;
+        h.Pz = tPz;
+      } else if (len_t > len_s) {
+        h.kind = 2;
+        h.index = idx_s;
+        h.Px = sh.x;
+        h.Py = sh.y;
+        h.Pz = sh.z;
+      }
+    }
+  }
+  const bool hit = live && h.kind != 0;
+  if (!__any(hit)) {
+    out.sp = sp;
+    return out;
+  }
+  Surface sf;
+  float kr = 0.f, kt = 0.f, ior = 1.f, wl = 0.f;
+  if (hit) {
+    sf = surface_at(sc, h);
+    const float4 m = material_at(sc, h);
+    kr = m.x;
+    kt = m.y;
+    ior = m.z > 0.f ? m.z : 1.0f;
+    wl = wgt * ((1.0f - kr) - kt);
+  }
+  const bool lit = hit && wl >= RT_MIN_WEIGHT;
+  if (__any(lit)) {
+    for (int l = 0; l < sc.l_size; l++) { // renderer.cpp:82
+      float fColor[3] = {0, 0, 0};
+      float lx = 0, ly = 0, lz = 0, angle = 0;
+      bool blocked = false;
+      if (lit) {
+        angle = phong_light(sf, h, dx, dy, dz, sc.lights[l], fColor, lx, ly, lz);
+        // renderer.cpp:119: the shadow ray starts exactly at P; its triangles here
+        float len_t = RT_INF, tx, ty, tz;
+        int idx_t = -1;
+        lane_triangles(sc, true, h.Px, h.Py, h.Pz, lx, ly, lz, len_t, idx_t, tx, ty, tz);
+        blocked = idx_t >= 0;
+        if (blocked)
+          out.n_rays++; // traced to the end here; the others are counted by the walk
+      }
+      const uint32_t c0 = (uint32_t)((fColor[0] * angle) * wl),
+                     c1 = (uint32_t)((fColor[1] * angle) * wl),
+                     c2 = (uint32_t)((fColor[2] * angle) * wl);
+      const uint32_t packed = (c0 & 0x3ffu) | ((c1 & 0x3ffu) << 10) | ((c2 & 0x3ffu) << 20);
+      sp = stack_push(stack, sp, cap, overflow, lit && !blocked,
+                      make_float4(h.Px, h.Py, h.Pz, __uint_as_float(pixel | RT_ITEM_SHADOW)),
+                      make_float4(lx, ly, lz, __uint_as_float(packed)));
+    }
+  }
+  const bool deeper = hit && (int)depth < max_depth;
+  const bool want_t = deeper && kt > 0.f && (wgt * kt >= RT_MIN_WEIGHT);
+  const bool want_r = deeper && kr > 0.f && (wgt * kr >= RT_MIN_WEIGHT);
+  if (__any(want_t)) {
+    float rx = 0, ry = 0, rz = 0;
+    if (want_t)
+      refract3(dx, dy, dz, sf.nx, sf.ny, sf.nz, ior, rx, ry, rz);
+    sp = stack_push(stack, sp, cap, overflow, want_t, make_float4(h.Px, h.Py, h.Pz, wgt * kt),
+                    make_float4(rx, ry, rz, __uint_as_float((pixel << 6) | (depth + 1))));
+  }
+  if (__any(want_r)) {
+    float rx = 0, ry = 0, rz = 0;
+    if (want_r) {
+      reflect3(dx, dy, dz, sf.nx, sf.ny, sf.nz, rx, ry, rz);
+      normalize3(rx, ry, rz);
+    }
+    sp = stack_push(stack, sp, cap, overflow, want_r, make_float4(h.Px, h.Py, h.Pz, wgt * kr),
+                    make_float4(rx, ry, rz, __uint_as_float((pixel << 6) | (depth + 1))));
+  }
+  out.sp = sp;
+  return out;
+}
+
+// k_trace — see the head of this file.  Grid: any number of 256-thread blocks;
+// wave w of the grid owns stack[w * stack_cap ...] and hits[w * hit_cap ...].
+__global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t seg = my_segment();
+  uint32_t n_in = t.in.count[seg * CTL_WORDS];
+  if (n_in > t.in.seg_capacity)
+    n_in = t.in.seg_capacity;
+  const size_t seg_base = (size_t)seg * t.in.seg_capacity;
+  uint32_t *const cursor = t.cursor + seg * CTL_WORDS;
+  const size_t wave_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  float4 *const stack = t.stack + 2 * wave_id * t.stack_cap;
+  float4 *const hits = t.hits + 3 * wave_id * t.hit_cap;
+  float4 *const save = t.save + TRACE_SAVE_WORDS / 4 * 64 * wave_id + lane; // [k * 64 + lane]
+  uint32_t sp_w = 0;   // items on the wave's stack (the same in every lane)
+  uint32_t n_hits = 0; // hit records waiting to be shaded (the same in every lane)
+
+  enum { EMPTY = 0, BUSY = 1, DRAIN = 2 }; // DRAIN: walk over, parked leaves left
+  int state = EMPTY;
+  bool shadow = false;
+  float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa; // the lane's item
+  float a = 0, a4 = 0, ix = 0, iy = 0, iz = 0, ida = 0;
+  float len_s = RT_INF, bound = RT_INF;
+  int idx_s = -1;
+  float sPx = 0, sPy = 0, sPz = 0;
+  __shared__ int lds_words[LDS_STACK_WORDS];
+  LdsStack stack_l;
+  stack_l.lds = lds_words + threadIdx.x;
+  int sp = 0, node = 0;
+  __shared__ int park_words[PARK_SLOTS * 256];
+  int *const park = park_words + threadIdx.x; // park[k * 256]: this lane's k-th parked leaf
+  int n_park = 0;
+  uint32_t n_rays = 0;
+  bool drained = false; // the frame's queue has nothing left for this block
+
+  auto leaf = [&](int slot) -> bool {
+    return leaf_test(sc, slot, a, a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, len_s, idx_s, sPx, sPy,
+                     sPz);
+  };
+
+  while (true) {
+    const int n_free = __builtin_popcountll(__ballot(state != BUSY));
+    const bool more = sp_w > 0 || !drained;
+    if (n_free == 64 || (more && n_free >= t.fetch_at)) {
+      // ---- work off parked leaves, all lanes together: the cheap screen on every
+      // parked leaf first, then the full test only as often as the busiest lane
+      // has passers ----
+      {
+        unsigned pass = 0;
+        for (int k = 0; __any(k < n_park); k++)
+          if (k < n_park &&
+              leaf_screen(sc, park[k * 256], a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z))
+            pass |= 1u << k;
+        n_park = 0;
+        while (__any(pass != 0)) {
+          if (pass != 0) {
+            const int slot = park[(__builtin_ctz(pass)) * 256];
+            pass &= pass - 1;
+            if (!(shadow && idx_s >= 0) && leaf(slot)) {
+              if (shadow)
+                state = DRAIN; // occluded: nothing more to find
+              else
+                bound = fminf(bound, len_s);
+            }
+          }
+        }
+      }
+      // ---- hand in finished items ----
+      {
+        const bool done = state == DRAIN;
+        if (done && shadow && idx_s < 0) // unoccluded: renderer.cpp:119-127 as an integer sum
+          add_light(t.extra, __float_as_uint(qa.w) & ~RT_ITEM_SHADOW, __float_as_uint(qb.w));
+        const bool rec = done && !shadow;
+        const unsigned long long m = __ballot(rec);
+        if (rec) {
+          float4 *r = hits + 3 * (size_t)(n_hits + (uint32_t)__builtin_popcountll(
+                                                       m & ((1ull << lane) - 1ull)));
+          r[0] = qa;
+          r[1] = qb;
+          r[2] = make_float4(sPx, sPy, sPz, __int_as_float(idx_s));
+        }
+        n_hits += (uint32_t)__builtin_popcountll(m);
+        if (done)
+          state = EMPTY;
+      }
+      // ---- shade the waiting hits, 64 at a time (the last few when nothing else is left) ----
+      if (n_hits >= 64 || (n_hits > 0 && sp_w == 0 && drained)) {
+        // walks in progress step aside: their state goes to the wave's save area
+        save[0 * 64] = qa;
+        save[1 * 64] = qb;
+        save[2 * 64] = make_float4(len_s, bound, __int_as_float(idx_s), sPx);
+        save[3 * 64] = make_float4(sPy, sPz, __int_as_float(sp), __int_as_float(node));
+        save[4 * 64] = make_float4(__int_as_float(n_park | (state << 8) | ((int)shadow << 16)),
+                                   __uint_as_float(n_rays), 0.f, 0.f);
+        uint32_t shade_rays = 0;
+        while (n_hits >= 64 || (n_hits > 0 && sp_w == 0 && drained)) {
+          const uint32_t n = n_hits < 64 ? n_hits : 64;
+          n_hits -= n;
+          const ShadeResult r =
+              trace_shade(sc, stack, sp_w, t.stack_cap, t.overflow, hits, n_hits, n, t.max_depth);
+          sp_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.sp);
+          shade_rays += r.n_rays;
+        }
+        // nothing computed before this point may be carried in registers past it:
+        // the walk state below is what the loads return
+        asm volatile("" ::: "memory");
+        {
+          const float4 s2 = save[2 * 64], s3 = save[3 * 64], s5 = save[4 * 64];
+          qa = save[0 * 64];
+          qb = save[1 * 64];
+          len_s = s2.x;
+          bound = s2.y;
+          idx_s = __float_as_int(s2.z);
+          sPx = s2.w;
+          sPy = s3.x;
+          sPz = s3.y;
+          sp = __float_as_int(s3.z);
+          node = __float_as_int(s3.w);
+          const int packed = __float_as_int(s5.x);
+          n_park = packed & 0xff;
+          state = (packed >> 8) & 0xff;
+          shadow = ((packed >> 16) & 1) != 0;
+          n_rays = __float_as_uint(s5.y) + shade_rays;
+          // per-ray constants of the walk, by the operations that made them at the fetch
+          a = dot3(qb.x, qb.y, qb.z, qb.x, qb.y, qb.z);
+          a4 = 4.0f * a;
+          const SphWalkRay wr = sph_walk_ray(qb.x, qb.y, qb.z, a);
+          ix = wr.ix;
+          iy = wr.iy;
+          iz = wr.iz;
+          ida = wr.ida;
+        }
+      }
+      // ---- fetch: the wave's own stack first, then the frame's queue ----
+      {
+        unsigned long long e = __ballot(state == EMPTY);
+        int n_e = __builtin_popcountll(e);
+        bool got = false;
+        if (n_e && sp_w) {
+          const uint32_t k = sp_w < (uint32_t)n_e ? sp_w : (uint32_t)n_e;
+          const uint32_t mine = (uint32_t)__builtin_popcountll(e & ((1ull << lane) - 1ull));
+          if (state == EMPTY && mine < k) {
+            const size_t s = (size_t)(sp_w - 1 - mine);
+            qa = stack[2 * s];
+            qb = stack[2 * s + 1];
+            got = true;
+          }
+          sp_w -= k;
+        }
+        e = __ballot(state == EMPTY && !got);
+        n_e = __builtin_popcountll(e);
+        if (n_e && !drained) {
+          const int leader = __builtin_ctzll(e);
+          uint32_t base = 0;
+          if (lane == leader)
+            base = atomicAdd(cursor, (uint32_t)n_e);
+          base = __builtin_amdgcn_readlane(base, leader);
+          if (base + (uint32_t)n_e >= n_in)
+            drained = true;
+          if (state == EMPTY && !got) {
+            const uint32_t r = base + (uint32_t)__builtin_popcountll(e & ((1ull << lane) - 1ull));
+            if (r < n_in) {
+              qa = t.in.items[2 * (seg_base + r)];
+              qb = t.in.items[2 * (seg_base + r) + 1];
+              got = true;
+            }
+          }
+        }
+        if (got) {
+          shadow = (__float_as_uint(qa.w) & RT_ITEM_SHADOW) != 0;
+          n_rays++;
+          len_s = RT_INF;
+          idx_s = -1;
+          bound = RT_INF;
+          sp = 0;
+          node = 0;
+          n_park = 0;
+          state = BUSY;
+          a = dot3(qb.x, qb.y, qb.z, qb.x, qb.y, qb.z); // maths.cpp:127
+          a4 = 4.0f * a;
+          const SphWalkRay wr = sph_walk_ray(qb.x, qb.y, qb.z, a);
+          ix = wr.ix;
+          iy = wr.iy;
+          iz = wr.iz;
+          ida = wr.ida;
+          const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
+          if (!(a > 0.f) || sc.s_size == 0) {
+            state = DRAIN; // no sphere can be hit (rt_device.h, beam screen notes)
+          } else if (!sane) {
+            // out-of-range direction length: this lane tests every sphere
+            for (int i = 0; i < sc.s_size; i++) {
+              const float4 g = sc.sph_geo[i];
+              float Px, Py, Pz;
+              if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, Px,
+                               Py, Pz)) {
+                const float len = length3(Px, Py, Pz);
+                if (len_s > len) {
+                  len_s = len;
+                  idx_s = i;
+                  sPx = Px;
+                  sPy = Py;
+                  sPz = Pz;
+                  if (shadow)
+                    break;
+                }
+              }
+            }
+            state = DRAIN;
+          }
+        }
+      }
+      if (!__any(state != EMPTY) && sp_w == 0 && n_hits == 0 && drained)
+        break;
+      continue;
+    }
+
+    if (state == BUSY) {
+      // ---- one node visit: the bounds of its (up to four) children ----
+      int next = -1;
+      float next_near = RT_INF;
+      bool touch[BVH_WIDTH];
+      float near_key[BVH_WIDTH], entry_key[BVH_WIDTH];
+      const BvhNode N = sc.bvh[node];
+      bvh_visit2(N, qa.x, qa.y, qa.z, ix, iy, iz, ida, bound, touch, near_key, entry_key);
+#pragma unroll
+      for (int c = 0; c < BVH_WIDTH; c++) {
+        const int32_t link = N.link[c];
+        if (touch[c] && link < 0) {
+          // a touched leaf is parked (or, with every slot taken, tested now)
+          const int slot = (~link) >> 3;
+          if (n_park < PARK_SLOTS) {
+            park[n_park++ * 256] = slot;
+          } else if (leaf(slot)) {
+            if (!shadow)
+              bound = fminf(bound, len_s);
+          }
+        } else if (touch[c]) {
+          // shadow: the child entered first; else the child nearest to the world
+          // origin (it tightens `bound`); the others go on the lane's stack
+          const float key = shadow ? entry_key[c] : near_key[c];
+          int push = link;
+          if (key < next_near) {
+            push = next;
+            next = link;
+            next_near = key;
+          }
+          if (push >= 0)
+            stack_l.push(sp, push);
+        }
+      }
+      if (next < 0 && sp > 0)
+        next = stack_l.pop(sp);
+      if (next >= 0 && !(shadow && idx_s >= 0))
+        node = next;
+      else
+        state = DRAIN;
+    }
+  }
+  add_ray_count(t.ray_count, n_rays);
+}
+
+} // namespace rt

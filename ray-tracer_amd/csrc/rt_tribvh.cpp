@@ -340,6 +340,16 @@ void tri_bvh_build(const float *tris, int n, TriBvhHost &out) {
   out.valid = true;
   if (m == 0)
     return; // everything is loose or unhittable: no nodes
+  // Median splits quarter a range per level.  A walk keeps the node it visits
+  // next in a register and stacks at most three siblings per level: a tree deeper
+  // than the stack allows is not built (the triangles are then looped over).
+  int depth = 0;
+  for (long cnt = m; cnt > 1; depth++)
+    cnt = ((cnt + 1) / 2 + 1) / 2;
+  if ((BVH_WIDTH - 1) * std::max(depth, 1) > BVH_STACK) {
+    out.valid = false;
+    return;
+  }
   order.resize(m);
   std::iota(order.begin(), order.end(), 0);
   out.leaf_idx.reserve(m);

@@ -89,6 +89,20 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
   return false;
 }
 
+constexpr int PARK_SLOTS = 8; // parked leaves per lane (rt_walk.h, k_walk)
+
+// The discriminant screen of maths.cpp:132-133 for leaf slot `slot`: can the
+// exact test pass at all?  (The same b, c, products and comparison as
+// sphere_exact; a lane whose screen fails need not run the rest.)
+__device__ __forceinline__ bool leaf_screen(const SceneDev &sc, int slot, float a4, float ox,
+                                            float oy, float oz, float dx, float dy, float dz) {
+  const float4 g = sc.leaf_geo[slot];
+  const float Lx = ox - g.x, Ly = oy - g.y, Lz = oz - g.z;
+  const float b = 2.0f * dot3(dx, dy, dz, Lx, Ly, Lz);
+  const float c = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - g.w;
+  return !(b * b < a4 * c);
+}
+
 // k_walk — each lane walks one hierarchy (TRI: the triangles', else the
 // spheres') for one queue item at a time and fetches the next item when it is
 // done.
@@ -101,14 +115,33 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
 //                    walk which follows finds nothing to do and nothing to add.
 // Leaves are single primitives.  Running the exact test the moment a leaf is
 // touched would make every iteration of the wave pay for it with one or two lanes
-// active, so a lane parks up to four touched leaves and the whole wave works
-// them off together whenever it stops to refill.
+// active, so a lane parks up to PARK_SLOTS touched leaves (in LDS, word
+// slot * 256 + thread: conflict-free whatever the lanes' counts are) and the whole
+// wave works them off together whenever it stops to refill.  With four slots in
+// registers 29 % of the visits still had some lane test a leaf on the spot, a
+// couple of hundred instructions for one or two lanes each time.
 // (80 VGPRs, 6 waves per SIMD for the sphere walk.  Forcing 7 or 8 waves makes it
 // spill 8 or 16 registers and costs more than the occupancy brings: 8.44 and
 // 9.42 ms per depth-8 frame against 8.17.)
+#ifdef RT_STAMPS
+// Diagnostic build only (make stamps): where a walking wave's cycles go.
+// [0] wave cycles in k_walk<false,false>, [1] in service phases, [2] from a node
+// load's issue to its data, [3] rest of the visits, [4] service phases, [5] visits,
+// [6] waves, [7] of the service time: waiting for the cursor atomic and the items,
+// [8] visits in which some lane tested a leaf on the spot (four already parked),
+// [9] lanes with a ray, summed over the visits
+__device__ unsigned long long g_stamps[16];
+#define RT_STAMP() __builtin_amdgcn_s_memtime()
+#endif
+
 template <bool ANY_HIT, bool TRI>
-__global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
+__global__ __launch_bounds__(256, TRI ? 5 : 6) void k_walk(SceneDev sc, WalkArgs w) {
   const int lane = threadIdx.x & 63;
+#ifdef RT_STAMPS
+  unsigned long long st_serv = 0, st_load = 0, st_visit = 0, st_fetch = 0, n_serv = 0, n_visit = 0;
+  unsigned long long n_over = 0, n_busy = 0;
+  const unsigned long long st_begin = RT_STAMP();
+#endif
   // this block serves segment (block % n_seg) of the queue together with the
   // other blocks of that residue; they share the segment's cursor
   const uint32_t seg = my_segment();
@@ -126,9 +159,11 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   float len_s = RT_INF, bound = RT_INF;
   int idx_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
-  int stack[BVH_STACK];
+  PrivateStack stack;
   int sp = 0, node = 0;
-  int p0 = 0, p1 = 0, p2 = 0, p3 = 0, n_park = 0;
+  __shared__ int park_words[PARK_SLOTS * 256];
+  int *const park = park_words + threadIdx.x; // park[k * 256]: this lane's k-th parked leaf
+  int n_park = 0;
   uint32_t n_rays = 0;
   bool drained = false;
 
@@ -142,11 +177,35 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
   while (true) {
     const int n_free = __builtin_popcountll(__ballot(state != BUSY));
     if (n_free == 64 || (!drained && n_free >= w.fetch_at)) {
+#ifdef RT_STAMPS
+      const unsigned long long st_a = RT_STAMP();
+      unsigned long long st_f0 = st_a, st_f1 = st_a;
+#endif
       // ---- work off parked leaves, all lanes together ----
+      if (!TRI) {
+        // spheres: first the cheap screen on every parked leaf (most fail it), then
+        // the full test only as often as the busiest lane has passers
+        unsigned pass = 0;
+        for (int k = 0; __any(k < n_park); k++)
+          if (k < n_park && leaf_screen(sc, park[k * 256], a4, ox, oy, oz, dx, dy, dz))
+            pass |= 1u << k;
+        n_park = 0;
+        while (__any(pass != 0)) {
+          if (pass != 0) {
+            const int slot = park[(__builtin_ctz(pass)) * 256];
+            pass &= pass - 1;
+            if (!(ANY_HIT && idx_s >= 0) && leaf(slot)) {
+              if (ANY_HIT)
+                state = DRAIN; // occluded: nothing more to find
+              else
+                bound = fminf(bound, len_s);
+            }
+          }
+        }
+      }
       while (__any(n_park > 0)) {
         if (n_park > 0) {
-          const int slot = n_park == 1 ? p0 : n_park == 2 ? p1 : n_park == 3 ? p2 : p3;
-          n_park--;
+          const int slot = park[--n_park * 256];
           if (!(ANY_HIT && idx_s >= 0) && leaf(slot)) {
             if (ANY_HIT)
               state = DRAIN; // occluded: nothing more to find
@@ -177,6 +236,9 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
         if (n_e) {
           const int leader = __builtin_ctzll(e);
           uint32_t base = 0;
+#ifdef RT_STAMPS
+          st_f0 = RT_STAMP();
+#endif
           if (lane == leader)
             base = atomicAdd(cursor, (uint32_t)n_e);
           base = __builtin_amdgcn_readlane(base, leader);
@@ -187,6 +249,10 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
             if (r < n_in) {
               const float4 qa = w.in.items[2 * (seg_base + r)],
                            qb = w.in.items[2 * (seg_base + r) + 1];
+#ifdef RT_STAMPS
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              st_f1 = RT_STAMP();
+#endif
               ray = r;
               ox = qa.x;
               oy = qa.y;
@@ -272,11 +338,22 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
           }
         }
       }
+#ifdef RT_STAMPS
+      st_f1 = __builtin_amdgcn_readfirstlane((int)(st_f1 - st_f0)); // any fetching lane's wait
+      st_fetch += st_f1 & 0xffffffffull;
+      st_serv += RT_STAMP() - st_a;
+      n_serv++;
+#endif
       if (!__any(state != EMPTY))
         break;
       continue;
     }
 
+#ifdef RT_STAMPS
+    const unsigned long long st_c = RT_STAMP();
+    unsigned long long st_d = st_c;
+    int st_over = 0;
+#endif
     if (state == BUSY) {
       // ---- one node visit: the bounds of its (up to four) children ----
       int next = -1;
@@ -296,6 +373,10 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
         }
       } else {
         const BvhNode N = sc.bvh[node];
+#ifdef RT_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_d = RT_STAMP();
+#endif
 #pragma unroll
         for (int c = 0; c < BVH_WIDTH; c++)
           links[c] = N.link[c];
@@ -306,21 +387,18 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
       for (int c = 0; c < BVH_WIDTH; c++) {
         const int32_t link = links[c];
         if (touch[c] && link < 0) {
-          // a touched leaf is parked (or, with four already parked, tested now)
+          // a touched leaf is parked (or, with every slot taken, tested now)
           const int slot = (~link) >> 3;
-          if (n_park < 4) {
-            if (n_park == 0)
-              p0 = slot;
-            else if (n_park == 1)
-              p1 = slot;
-            else if (n_park == 2)
-              p2 = slot;
-            else
-              p3 = slot;
-            n_park++;
-          } else if (leaf(slot)) {
-            if (!ANY_HIT)
-              bound = fminf(bound, len_s);
+          if (n_park < PARK_SLOTS) {
+            park[n_park++ * 256] = slot;
+          } else {
+#ifdef RT_STAMPS
+            st_over = 1;
+#endif
+            if (leaf(slot)) {
+              if (!ANY_HIT)
+                bound = fminf(bound, len_s);
+            }
           }
         } else if (touch[c]) {
           // visit the child nearest to the world origin next (it tightens
@@ -331,18 +409,45 @@ __global__ __launch_bounds__(256) void k_walk(SceneDev sc, WalkArgs w) {
             next = link;
             next_near = nears[c];
           }
-          if (push >= 0 && sp < BVH_STACK)
-            stack[sp++] = push;
+          if (push >= 0)
+            stack.push(sp, push);
         }
       }
       if (next < 0 && sp > 0)
-        next = stack[--sp];
+        next = stack.pop(sp);
       if (next >= 0 && !(ANY_HIT && idx_s >= 0))
         node = next;
       else
         state = DRAIN;
     }
+#ifdef RT_STAMPS
+    {
+      // a lane that took the branch has the load's stamp; the others did not load
+      const unsigned long long now = RT_STAMP();
+      const unsigned long long any_d = __builtin_amdgcn_readfirstlane((int)(st_d - st_c));
+      st_load += any_d & 0xffffffffull;
+      st_visit += now - st_c;
+      n_visit++;
+      if (__any(st_over))
+        n_over++;
+      n_busy += __builtin_popcountll(__ballot(state == BUSY || state == DRAIN));
+    }
+#endif
   }
+#ifdef RT_STAMPS
+  if (!ANY_HIT && !TRI && lane == 0) {
+    atomicAdd(&g_stamps[0], RT_STAMP() - st_begin);
+    atomicAdd(&g_stamps[1], st_serv);
+    atomicAdd(&g_stamps[2], st_load);
+    atomicAdd(&g_stamps[3], st_visit - st_load);
+    atomicAdd(&g_stamps[4], n_serv);
+    atomicAdd(&g_stamps[5], n_visit);
+    atomicAdd(&g_stamps[6], 1ull);
+    atomicAdd(&g_stamps[7], st_fetch);
+    atomicAdd(&g_stamps[8], n_over);
+    atomicAdd(&g_stamps[9], n_busy);
+  }
+#endif
   add_ray_count(w.ray_count, n_rays);
 }
 

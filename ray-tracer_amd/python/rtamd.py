@@ -168,6 +168,7 @@ def lib() -> C.CDLL:
     L.rt_set_screen.restype = None
     L.rt_scene_set_screen.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_set_side_stream.argtypes = [C.c_void_p, C.c_int]
+    L.rt_scene_set_one_launch.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_set_rays_per_pixel.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_queue_overflowed.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.gpu_render_unlit.argtypes = [C.POINTER(SceneDesc), C.POINTER(Camera), C.c_void_p,
@@ -303,6 +304,11 @@ class DeviceScene:
     def set_screen(self, mode):
         """rt_scene_set_screen: the work-avoidance mode of this scene's later frames."""
         _check(lib().rt_scene_set_screen(self.handle, _mode(mode)))
+
+    def set_one_launch(self, on: bool):
+        """rt_scene_set_one_launch: all bounce levels in one launch (default) or a
+        launch per stage and level."""
+        _check(lib().rt_scene_set_one_launch(self.handle, int(bool(on))))
 
     def set_side_stream(self, on: bool):
         """rt_scene_set_side_stream."""

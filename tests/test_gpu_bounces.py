@@ -133,18 +133,19 @@ def test_side_stream_and_mode_of_a_resident_scene(oracle):
     ids = torch.zeros(h, w, dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     with rtamd.DeviceScene(sc) as ds:
-        for side in (0, 1):
+        for side, one in ((0, 1), (0, 0), (1, 0)):
             for mode in ("auto", "off", "beam", "bvh"):
                 ds.set_side_stream(side)
+                ds.set_one_launch(one)
                 ds.set_screen(mode)
                 fb.zero_(), ids.zero_(), cnt.zero_()
                 ds.render_device(fb.data_ptr(), ids.data_ptr(), w, h, max_depth=6,
                                  dev_ray_count=cnt.data_ptr())
                 torch.cuda.synchronize()
                 assert not ds.queue_overflowed()
-                assert np.array_equal(ids.cpu().numpy(), io), (side, mode)
-                assert np.array_equal(fb.cpu().numpy(), fo), (side, mode)
-                assert int(cnt.item()) == no, (side, mode)
+                assert np.array_equal(ids.cpu().numpy(), io), (side, one, mode)
+                assert np.array_equal(fb.cpu().numpy(), fo), (side, one, mode)
+                assert int(cnt.item()) == no, (side, one, mode)
         with pytest.raises(rtamd.RtError):
             rtamd._check(rtamd.lib().rt_scene_set_screen(ds.handle, 9))
 
@@ -184,6 +185,15 @@ def test_queue_capacity_grows_when_rays_multiply(oracle):
     dev = torch.device("cuda", 0)
     out = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
     with rtamd.DeviceScene(sc) as ds:
+        # all levels in one launch: a wave works depth-first on a stack of its own,
+        # which this many rays per pixel does not fill
+        ds.render_device(out.data_ptr(), None, w, h, max_depth=depth)
+        torch.cuda.synchronize()
+        assert not ds.queue_overflowed()
+        assert np.array_equal(out.cpu().numpy(), fo)
+        # a launch per stage and level queues every level of the frame whole
+        ds.set_one_launch(False)
+        out.zero_()
         ds.render_device(out.data_ptr(), None, w, h, max_depth=depth)
         torch.cuda.synchronize()
         assert ds.queue_overflowed()
@@ -241,10 +251,12 @@ def test_10k_grid_4k_depth8_every_row_equals_the_plain_loop():
     sc = rtamd.material_grid_scene(100, 100)
     with rtamd.DeviceScene(sc) as ds:
         f0, i0, n0 = _device_frame(ds, 3840, 2160, 8, "off")
-        f1, i1, n1 = _device_frame(ds, 3840, 2160, 8, "auto")
-        assert n0 == n1
-        assert torch.equal(i0, i1)
-        assert torch.equal(f0, f1)
+        for one in (1, 0):   # all levels in one launch / a launch per stage and level
+            ds.set_one_launch(one)
+            f1, i1, n1 = _device_frame(ds, 3840, 2160, 8, "auto")
+            assert n0 == n1, one
+            assert torch.equal(i0, i1), one
+            assert torch.equal(f0, f1), one
 
 
 def test_mesh_80k_720p_depth4_every_row_equals_the_plain_loop():

@@ -19,13 +19,16 @@ name = sys.argv[1] if len(sys.argv) > 1 else "10k-spheres-4k-depth8"
 sc, w, h, depth = bench.build_scene(name)
 dev = torch.device("cuda", 0)
 SIDE = int(os.environ.get('SIDE', '0'))
+ONE = int(os.environ.get('ONE_LAUNCH', '1'))
+print(f'one launch {ONE}, side stream {SIDE}', flush=True)
 flights = [int(x) for x in os.environ.get('FLIGHTS', '1,2,3,4').split(',')]
-for n in (1, 2, 4, 8):
+for n in [int(x) for x in os.environ.get('SHARES', '1,2,4,8').split(',')]:
     base = None
     for flight in flights:
         scenes = [rtamd.DeviceScene(sc) for _ in range(flight)]
         for d in scenes:
             d.set_side_stream(SIDE)
+            d.set_one_launch(ONE)
         streams = [torch.cuda.Stream(device=dev) for _ in range(flight)]
         fbs = [torch.zeros(h, w, 4, dtype=torch.uint8, device=dev) for _ in range(flight)]
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -24,6 +24,9 @@ stream = torch.cuda.current_stream().cuda_stream
 print(f"{name}, bands of {band_rows} rows", flush=True)
 base = None
 with rtamd.DeviceScene(sc) as ds:
+    ds.set_one_launch(int(os.environ.get('ONE_LAUNCH', '1')))
+    ds.set_side_stream(int(os.environ.get('SIDE', '1')))
+    print(f"one launch {os.environ.get('ONE_LAUNCH', '1')}, side stream {os.environ.get('SIDE', '1')}", flush=True)
     for n in ([int(os.environ['RANK_SHARE_N'])] if 'RANK_SHARE_N' in os.environ else (1, 2, 4, 8)):
         def frame():
             ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth, band_rows=band_rows,
