@@ -14,7 +14,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC \
             -fno-fast-math -Wall -Wno-unused-function
 LIB      := $(CSRC)/librt_amd.so
 SRCS     := $(CSRC)/rt_kernels.hip $(CSRC)/rt_api.hip $(CSRC)/rt_bvh.cpp $(CSRC)/rt_tribvh.cpp
-HDRS     := $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/rt_bvh.h $(CSRC)/rt_tribvh.h $(CSRC)/rt_walk.h include/rt_amd.h
+HDRS     := $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/rt_bvh.h $(CSRC)/rt_tribvh.h $(CSRC)/rt_walk.h $(CSRC)/rt_trace.h include/rt_amd.h
 
 all: lib oracle
 

@@ -218,6 +218,17 @@ int rt_scene_set_side_stream(rt_scene *scene, int on);
  * counterpart in the reference.                                                */
 int rt_scene_set_one_launch(rt_scene *scene, int on);
 
+/* Stage times of a scene's frames, measured with HIP events on the frame's own
+ * stream (no counterpart in the reference).  After rt_scene_time_kernels(scene,
+ * 1) every rt_render_device call records events around its stages;
+ * rt_scene_kernel_times waits for the last frame and returns, in milliseconds,
+ * ms[0] the primary pass (k_render: ray generation, nearest hit, Phong and shadow
+ * rays of renderer.cpp:28-140), ms[1] all bounce levels (k_trace, or the
+ * launch-per-level chain; 0 without bounces), ms[2] the final sum into the
+ * framebuffer.                                                               */
+int rt_scene_time_kernels(rt_scene *scene, int on);
+int rt_scene_kernel_times(rt_scene *scene, float ms[3]);
+
 /* As rt_render_device, with a slow self-checking build of the kernel that
  * re-tests every sphere the screen dropped.  dev_stats (device, 16 x uint64,
  * zeroed by the caller) receives

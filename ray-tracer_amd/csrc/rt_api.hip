@@ -218,12 +218,17 @@ struct rt_scene {
   int rays_per_pixel = 4;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+  // rt_scene_time_kernels: events around the stages of the last frame
+  bool timing = false;
+  hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
+  int timed_stages = 0;
   // staging for gpu_check_intersection (grow-only)
   DevBuf<float> chk_in, chk_P;
   DevBuf<int32_t> chk_out;
 
   ~rt_scene() {
-    for (hipEvent_t e : {ev_eye, ev_frame, ev_fork[0], ev_fork[1], ev_join[0], ev_join[1]})
+    for (hipEvent_t e : {ev_eye, ev_frame, ev_fork[0], ev_fork[1], ev_join[0], ev_join[1], ev_t[0],
+                         ev_t[1], ev_t[2], ev_t[3]})
       if (e)
         (void)hipEventDestroy(e);
     if (side)
@@ -669,8 +674,15 @@ static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, con
     accel = RT_BEAM_APEX;
   else if (S->screen == 1 || S->screen == 3)
     accel = RT_ACCEL_BVH;
+  S->timed_stages = 0;
+  if (S->timing)
+    HIP_TRY(hipEventRecord(S->ev_t[0], st));
   HIP_TRY(rt::launch_render(sd, camera_dev(cam, fr->w, fr->h), f, bd, P.owned_tile_rows, accel,
                             (unsigned long long *)dev_verify, st));
+  if (S->timing) {
+    HIP_TRY(hipEventRecord(S->ev_t[1], st));
+    S->timed_stages = 1;
+  }
   if (!P.bounces)
     return RT_OK;
   // With a hierarchy each level runs as walk / shade / shadow-walk launches with
@@ -695,7 +707,13 @@ static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, con
     ta.max_depth = fr->max_depth;
     ta.fetch_at = rt::WALK_FETCH_AT;
     HIP_TRY(rt::launch_trace(sd, ta, (int)(A->have.trace_waves / 4), st));
+    if (S->timing)
+      HIP_TRY(hipEventRecord(S->ev_t[2], st));
     HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, (size_t)fr->w * fr->h, st));
+    if (S->timing) {
+      HIP_TRY(hipEventRecord(S->ev_t[3], st));
+      S->timed_stages = 3;
+    }
     return RT_OK;
   }
   bool joined[2] = {false, false};
@@ -790,7 +808,13 @@ static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, con
   for (int k = 0; k < 2; k++)
     if (joined[k])
       HIP_TRY(hipStreamWaitEvent(st, S->ev_join[k], 0));
+  if (S->timing)
+    HIP_TRY(hipEventRecord(S->ev_t[2], st));
   HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, (size_t)fr->w * fr->h, st));
+  if (S->timing) {
+    HIP_TRY(hipEventRecord(S->ev_t[3], st));
+    S->timed_stages = 3;
+  }
   return RT_OK;
 }
 
@@ -948,6 +972,31 @@ int rt_scene_set_screen(rt_scene *S, int mode) {
   if (mode < 0 || mode > 3)
     return fail(RT_ERR_BAD_ARG, "screen mode %d outside 0..3", mode);
   S->screen = mode;
+  return RT_OK;
+}
+
+int rt_scene_time_kernels(rt_scene *S, int on) {
+  if (!S)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  HIP_TRY(hipSetDevice(S->device));
+  if (on && !S->ev_t[0])
+    for (hipEvent_t &e : S->ev_t)
+      HIP_TRY(hipEventCreate(&e));
+  S->timing = on != 0;
+  S->timed_stages = 0;
+  return RT_OK;
+}
+
+int rt_scene_kernel_times(rt_scene *S, float ms[3]) {
+  if (!S || !ms)
+    return fail(RT_ERR_BAD_ARG, "scene or result is NULL");
+  if (!S->timing || S->timed_stages == 0)
+    return fail(RT_ERR_BAD_ARG, "no timed frame (rt_scene_time_kernels, then render)");
+  HIP_TRY(hipSetDevice(S->device));
+  ms[0] = ms[1] = ms[2] = 0.f;
+  HIP_TRY(hipEventSynchronize(S->ev_t[S->timed_stages]));
+  for (int k = 0; k < S->timed_stages; k++)
+    HIP_TRY(hipEventElapsedTime(&ms[k], S->ev_t[k], S->ev_t[k + 1]));
   return RT_OK;
 }
 

@@ -169,6 +169,8 @@ def lib() -> C.CDLL:
     L.rt_scene_set_screen.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_set_side_stream.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_set_one_launch.argtypes = [C.c_void_p, C.c_int]
+    L.rt_scene_time_kernels.argtypes = [C.c_void_p, C.c_int]
+    L.rt_scene_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.rt_scene_set_rays_per_pixel.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_queue_overflowed.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.gpu_render_unlit.argtypes = [C.POINTER(SceneDesc), C.POINTER(Camera), C.c_void_p,
@@ -304,6 +306,17 @@ class DeviceScene:
     def set_screen(self, mode):
         """rt_scene_set_screen: the work-avoidance mode of this scene's later frames."""
         _check(lib().rt_scene_set_screen(self.handle, _mode(mode)))
+
+    def time_kernels(self, on: bool = True):
+        """rt_scene_time_kernels: record events around the stages of later frames."""
+        _check(lib().rt_scene_time_kernels(self.handle, int(bool(on))))
+
+    def kernel_times(self):
+        """rt_scene_kernel_times: (primary pass, bounce levels, final sum) of the last
+        frame in ms."""
+        ms = (C.c_float * 3)()
+        _check(lib().rt_scene_kernel_times(self.handle, ms))
+        return float(ms[0]), float(ms[1]), float(ms[2])
 
     def set_one_launch(self, on: bool):
         """rt_scene_set_one_launch: all bounce levels in one launch (default) or a
