@@ -24,6 +24,10 @@ import rtamd  # noqa: E402
 from rt_shard import BandPlan  # noqa: E402
 
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32, FMA counted as 2 flop
+# The path may not fuse (results must equal the reference's unfused arithmetic),
+# so a lane does at most one flop per vector instruction: half of the peak above.
+PEAK_UNFUSED_TLANEOPS = PEAK_FP32_VALU_TFLOPS / 2
+STAGES = ("primary", "bounce", "compose")   # rt_scene_kernel_times order
 PEAK_HBM_GBS = 8000.0           # MI355X HBM3E
 FLOP_PER_SPHERE_TEST = 25       # maths.cpp:126-133 up to the discriminant test
 FLOP_PER_TRIANGLE_TEST = 107    # maths.cpp:68-116 full path
@@ -103,6 +107,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plain-loop", action="store_true",
+                    help="skip the every-ray-every-primitive leg (profiling runs)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for --gpus > 1; gloo stages the bands through "
                          "host memory and exists to rehearse the multi-rank path on one GPU")
@@ -223,7 +229,6 @@ def main():
     # device time of one frame's launches, first to last; with several frames in
     # flight these intervals overlap, so this is a frame's latency, not 1/throughput
     frame_latency_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
-    kernel_ms = [dt / args.steps * 1e3] if n_buf > 1 else [e0.elapsed_time(e1) for e0, e1 in events]
 
     for sl in slots:
         if sl.scene.queue_overflowed():
@@ -235,14 +240,31 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_rays = int(rays.item())
     dt = float(tmax.item())
+    my_rays_per_frame = int(cnt.item()) / args.steps
+
+    # ---- one frame at a time, stage by stage (not part of `value`) ----
+    # HIP events recorded by the library on the frame's own stream around the
+    # primary pass (k_render), the bounce levels (k_trace, or the chain of
+    # k_walk / k_shade launches) and the final sum (k_compose).
+    def staged_frames(n):
+        sl = slots[0]
+        sl.scene.time_kernels(True)
+        per = []
+        for _ in range(n):
+            with torch.cuda.stream(sl.stream):
+                sl.scene.render_device(sl.fb.data_ptr(), None, w, h, max_depth=depth,
+                                       band_rows=band_rows, band_index=rank, band_count=world,
+                                       stream=sl.stream.cuda_stream, dev_ray_count=cnt.data_ptr())
+            per.append(sl.scene.kernel_times())   # waits for the frame
+        sl.scene.time_kernels(False)
+        return [float(np.mean([p[k] for p in per])) for k in range(3)]
+
+    staged_frames(2)
+    stage_ms = staged_frames(min(10, max(2, args.steps)))
+    one_frame_ms = float(sum(stage_ms))
 
     if rank == 0:
         value = total_rays / dt / 1e6
-        # roofline of the dominant kernel (k_render) on this rank: algorithmic
-        # FLOP of the rays this rank traced per launch / mean launch duration
-        my_rays_per_launch = int(cnt.item()) / args.steps
-        k_ms = float(np.mean(kernel_ms))
-        achieved = my_rays_per_launch * n_tests_per_ray / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -253,51 +275,36 @@ def main():
                        "spheres": sc.s_size, "triangles": sc.t_size, "lights": sc.l_size,
                        "materials": sc.mat_sphere is not None,
                        "rays_per_frame": total_rays // args.steps,
-                       "sharding": f"row bands of {band_rows}, round-robin over {world} GPU(s)"},
-            "roofline": {"bound": "valu_fp32", "achieved": achieved,
-                         "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": measured_traffic(name),
-                         "kernel": "device work of one rt_render_device call: k_render, then per "
-                                   "bounce level k_walk / k_shade / k_walk, k_compose",
-                         "kernel_ms": k_ms,
-                         "flop_per_ray": n_tests_per_ray,
-                         "note": "algorithmic FLOP = rays x (25 x spheres + 107 x triangles); "
-                                 "parity forbids FMA, so 1 flop/lane/instr caps executed "
-                                 "arithmetic at 1/2 of peak; with the beam screen on most "
-                                 "of that arithmetic is proven unnecessary and skipped, so "
-                                 "frac can exceed 1 (plain_loop = screen off)"},
+                       "sharding": f"row bands of {band_rows}, round-robin over {world} GPU(s)",
+                       "screen": args.screen, "frames_in_flight": n_buf,
+                       "one_launch": args.one_launch},
+            "frame_latency_ms": frame_latency_ms,
+            # the same frame with nothing else on the GPU: sum of the three stages
+            "one_frame_ms": one_frame_ms,
+            "one_frame_mrays_per_s": my_rays_per_frame / (one_frame_ms * 1e-3) / 1e6,
         }
-        # the same launches against the HBM roofline (not the bound of this path:
-        # the scene sits in L2; reported so that both rooflines can be read off)
-        traffic = out["roofline"]["traffic"]
-        if traffic:
-            gbs = traffic / (k_ms * 1e-3) / 1e9
-            out["roofline"]["hbm"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": gbs / PEAK_HBM_GBS}
-        out["config"]["screen"] = args.screen
-        out["config"]["frames_in_flight"] = n_buf
-        out["frame_latency_ms"] = frame_latency_ms
-        if world == 1 and args.screen != "off" and sc.t_size + sc.s_size > PLAIN_LOOP_MAX_PRIMS:
-            out["roofline"]["plain_loop"] = None   # minutes per frame at this size: not run
-        elif world == 1 and args.screen != "off":
-            # the same frame with the screen off: the brute-force formulation the
-            # FP32 roofline is defined on (every ray against every primitive)
-            for sl in slots:
+        out["roofline"] = roofline(name, args, world, stage_ms, my_rays_per_frame, n_tests_per_ray)
+        if world == 1 and args.screen != "off" and not args.no_plain_loop:
+            if sc.t_size + sc.s_size > PLAIN_LOOP_MAX_PRIMS:
+                out["roofline"]["plain_loop"] = None   # minutes per frame at this size: not run
+            else:
+                # the same frame with every ray tested against every primitive: the
+                # formulation whose FLOP count the FP32 roofline is defined on
+                sl = slots[0]
                 sl.scene.set_screen("off")
-            step(False)
-            torch.cuda.synchronize()
-            events.clear()
-            for _ in range(2):
-                step(True)
-            torch.cuda.synchronize()
-            for sl in slots:
+                staged_frames(1)
+                bf_ms = float(sum(staged_frames(2)))
                 sl.scene.set_screen(args.screen)
-            bf_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
-            bf = my_rays_per_launch * n_tests_per_ray / (bf_ms * 1e-3) / 1e12
-            out["roofline"]["plain_loop"] = {
-                "kernel_ms": bf_ms, "achieved": bf, "frac": bf / PEAK_FP32_VALU_TFLOPS,
-                "mrays_per_s": my_rays_per_launch / (bf_ms * 1e-3) / 1e6}
+                bf = my_rays_per_frame * n_tests_per_ray / (bf_ms * 1e-3) / 1e12
+                out["roofline"]["plain_loop"] = {
+                    "kernel_ms": bf_ms, "achieved": bf, "peak": PEAK_FP32_VALU_TFLOPS,
+                    "unit": "TFLOP/s", "frac": bf / PEAK_FP32_VALU_TFLOPS,
+                    "flop_per_ray": n_tests_per_ray,
+                    "mrays_per_s": my_rays_per_frame / (bf_ms * 1e-3) / 1e6,
+                    "note": "algorithmic FLOP = rays x (25 x spheres + 107 x triangles) over the "
+                            "time of the frame rendered by the plain loops (rt_scene_set_screen 0)"}
+                # how much of that arithmetic the shipped path proves unnecessary
+                out["roofline"]["work_avoidance_factor"] = bf_ms / one_frame_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, w, h, depth)
         print(json.dumps(out))
@@ -307,15 +314,65 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(workload):
-    """HBM bytes per frame from rocprofv3 counters (FETCH_SIZE x 2 on gfx950 +
-    WRITE_SIZE), collected by tools/profile.sh in a run of its own and kept in
-    profiles/traffic.json; None when that workload has not been profiled."""
+def profiled_counters(workload):
+    """Per-frame instruction and traffic counts of the library's kernels, by
+    stage, from rocprofv3 --pmc passes of this same program with one frame in
+    flight (tools/profile.sh writes them; instruction counts do not depend on
+    timing).  None when that workload has not been profiled."""
     try:
-        with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_frame")
+        with open(os.path.join(REPO, "profiles", "counters.json")) as f:
+            return json.load(f).get(workload)
     except (OSError, ValueError):
         return None
+
+
+def roofline(name, args, world, stage_ms, rays_per_frame, flop_per_ray):
+    """Where the kernels of one frame sit against the vector-FP32 ceiling.
+
+    achieved = executed vector lane-operations per second of the stage that takes
+    longest: SQ_INSTS_VALU (wave instructions per launch, from the committed
+    counter passes) x active lanes per instruction / the stage's duration
+    measured here with HIP events.  A lane-operation is at most one flop because
+    this path may not fuse, so the ceiling is half the FMA peak.  The fraction
+    cannot exceed 1 whatever work the hierarchies avoid."""
+    prof = profiled_counters(name) if (world == 1 and args.screen == "auto") else None
+    stages = {}
+    for k, st in enumerate(STAGES):
+        e = {"ms": stage_ms[k]}
+        c = (prof or {}).get("stages", {}).get(st)
+        if c and stage_ms[k] > 0 and (prof or {}).get("one_launch", 1) == args.one_launch:
+            lane_ops = c["valu_wave_insts"] * c["lanes_per_valu_inst"]
+            e.update({
+                "kernels": c["kernels"], "ms_rocprof": c["ms"],
+                "valu_wave_insts": c["valu_wave_insts"],
+                "lanes_per_valu_inst": c["lanes_per_valu_inst"],
+                "tlaneops_per_s": lane_ops / (stage_ms[k] * 1e-3) / 1e12,
+                "frac": lane_ops / (stage_ms[k] * 1e-3) / 1e12 / PEAK_UNFUSED_TLANEOPS,
+                # wave instructions x 2 cycles over the SIMD-cycles of the launch
+                "valu_issue_frac": c["valu_wave_insts"] * 2 /
+                                   (1024 * c["clock_ghz"] * 1e9 * stage_ms[k] * 1e-3),
+                "hbm_bytes": c["hbm_bytes"],
+                "hbm_gbs": c["hbm_bytes"] / (stage_ms[k] * 1e-3) / 1e9,
+            })
+        stages[st] = e
+    dom = max(STAGES, key=lambda st: stages[st]["ms"])
+    d = stages[dom]
+    r = {"bound": "valu_fp32", "kernel": dom, "kernel_ms": d["ms"],
+         "achieved": d.get("tlaneops_per_s"), "peak": PEAK_UNFUSED_TLANEOPS, "unit": "TFLOP/s",
+         "frac": d.get("frac"), "traffic": d.get("hbm_bytes"),
+         "stages": stages,
+         "note": "achieved = vector lane-operations executed per second by the longest stage "
+                 "(wave instructions x active lanes, rocprofv3 counters in profiles/counters.json) "
+                 "over its duration measured here with HIP events, one frame on the GPU; peak = "
+                 "157.3 / 2 because results must equal unfused arithmetic (1 flop per lane and "
+                 "instruction at most); not every vector instruction is a flop, so this bounds "
+                 "the flop rate from above"}
+    if d.get("hbm_bytes") is not None:
+        r["hbm"] = {"achieved": d["hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": d["hbm_gbs"] / PEAK_HBM_GBS}
+    if prof is None:
+        r["note"] += "; no counter passes committed for this workload/mode: achieved is null"
+    return r
 
 
 def default_workload():
