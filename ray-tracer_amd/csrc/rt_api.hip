@@ -191,6 +191,8 @@ struct rt_scene {
   DevBuf<float4> leaf_geo;
   DevBuf<int32_t> leaf_idx;
   bool has_bvh = false;
+  int bvh_depth = 0;     // levels of inner nodes
+  size_t bvh_nodes = 0;
   DevBuf<rt::TriNode> tbvh;
   DevBuf<rt::TriLeaf> tleaf;
   DevBuf<int32_t> tloose;
@@ -381,6 +383,8 @@ int scene_build(rt_scene *S, const scene_desc *s) {
     rt::BvhHost H;
     rt::bvh_build(s->spheres, s->radius, s->s_size, H);
     S->has_bvh = H.valid;
+    S->bvh_depth = H.depth;
+    S->bvh_nodes = H.nodes.size();
     if (H.valid) {
       if ((rc = upload(S->bvh, H.nodes.data(), H.nodes.size())) ||
           (rc = upload(S->leaf_idx, H.leaf_idx.data(), H.leaf_idx.size())))
@@ -444,12 +448,14 @@ int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
 }
 
 // Does a frame of this scene run its bounce levels as one launch (rt_trace.h)?
-// That kernel walks the sphere hierarchy and loops over the triangles; scenes
-// with a triangle hierarchy, scenes without any hierarchy, more lights than one
-// group, and the largest queue setting (which must not be able to overflow) take
-// the launch-per-level path.
+// That kernel walks the sphere hierarchy (a lane's stack of nodes in LDS, sized
+// for trees of TRACE_MAX_TREE_DEPTH levels) and loops over the triangles; scenes
+// with a triangle hierarchy, scenes without any hierarchy or with a deeper one,
+// more lights than one group, and the largest queue setting (which must not be
+// able to overflow) take the launch-per-level path.
 bool uses_trace(const rt_scene *S) {
   return S->has_bvh && S->screen != 0 && !S->has_tbvh && S->l_size <= kLightGroup &&
+         S->bvh_depth <= rt::TRACE_MAX_TREE_DEPTH && S->bvh_nodes <= rt::TRACE_MAX_NODES &&
          S->rays_per_pixel < 256 && S->one_launch;
 }
 

@@ -178,6 +178,41 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
   return out;
 }
 
+// ---- the lane's two small arrays in LDS -------------------------------------------
+// Word (row * 256 + thread): the 64 lanes of a wave hit 64 different banks whatever
+// row each of them is at.  Rows 0 .. TRACE_STACK_ROWS-1 are the lane's stack of
+// nodes still to visit, the next TRACE_PARK_ROWS its parked leaves; five blocks of
+// 32 KB fill a CU's LDS.  A walk stacks at most three siblings per level of inner
+// nodes below which there are inner nodes (and one row more takes the stores that
+// do not count), so TRACE_STACK_ROWS rows serve trees of up to
+// TRACE_MAX_TREE_DEPTH levels of inner nodes (65 536 spheres when balanced);
+// the host sends deeper trees to the launch-per-level kernels.  A stack entry is
+// (16 bits of ordering key) << 16 | node index, hence at most 65 535 nodes.
+//
+// The visit below is written without branches: every child is parked and pushed
+// by an unconditional store whose row only advances when the child qualifies (a
+// store that does not count is overwritten by the next one), and the touched
+// inner children are put in order by a five-step network of integer min / max on
+// the packed entries.  The straight-line form is less than half the instructions
+// of the branching one (per child a dozen exec-mask branches, each a handful of
+// scalar instructions and a wait for them), and a walk's pace is set by how many
+// instructions a wave issues per visit.  For the stores to stay in range a lane
+// never enters a visit with more than TRACE_PARK_FULL parked leaves: the wave works
+// the parked leaves off first (all lanes together, as at every refill).
+constexpr int TRACE_STACK_ROWS = 22;
+constexpr int TRACE_PARK_ROWS = 10;
+constexpr int TRACE_PARK_FULL = TRACE_PARK_ROWS - BVH_WIDTH;
+static_assert(3 * (TRACE_MAX_TREE_DEPTH - 1) + 1 <= TRACE_STACK_ROWS,
+              "three rows per level but the last, and the row the stores that do not count land in");
+static_assert((TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 1024 <= 32768, "five blocks per CU");
+
+// Sorts two packed entries: a <= b afterwards.
+__device__ __forceinline__ void order2(uint32_t &a, uint32_t &b) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+
 // k_trace — see the head of this file.  Grid: any number of 256-thread blocks;
 // wave w of the grid owns stack[w * stack_cap ...] and hits[w * hit_cap ...].
 __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
@@ -203,12 +238,10 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   float len_s = RT_INF, bound = RT_INF;
   int idx_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
-  __shared__ int lds_words[LDS_STACK_WORDS];
-  LdsStack stack_l;
-  stack_l.lds = lds_words + threadIdx.x;
+  __shared__ uint32_t lds_words[(TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 256];
+  uint32_t *const stack_l = lds_words + threadIdx.x; // stack_l[k * 256]: k-th stacked node
+  uint32_t *const park = stack_l + TRACE_STACK_ROWS * 256; // park[k * 256]: k-th parked leaf
   int sp = 0, node = 0;
-  __shared__ int park_words[PARK_SLOTS * 256];
-  int *const park = park_words + threadIdx.x; // park[k * 256]: this lane's k-th parked leaf
   int n_park = 0;
   uint32_t n_rays = 0;
   bool drained = false; // the frame's queue has nothing left for this block
@@ -221,20 +254,36 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   while (true) {
     const int n_free = __builtin_popcountll(__ballot(state != BUSY));
     const bool more = sp_w > 0 || !drained;
-    if (n_free == 64 || (more && n_free >= t.fetch_at)) {
+    if (n_free == 64 || (more && n_free >= t.fetch_at) ||
+        __any(state == BUSY && n_park > TRACE_PARK_FULL)) {
       // ---- work off parked leaves, all lanes together: the cheap screen on every
       // parked leaf first, then the full test only as often as the busiest lane
       // has passers ----
       {
+        // four parked leaves at a time: their rows, then their records, then the
+        // arithmetic, so that a lane waits once per four leaves and not twice per leaf
         unsigned pass = 0;
-        for (int k = 0; __any(k < n_park); k++)
-          if (k < n_park &&
-              leaf_screen(sc, park[k * 256], a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z))
-            pass |= 1u << k;
+        for (int k0 = 0; __any(k0 < n_park); k0 += 4) {
+          uint32_t slot[4];
+          float4 g[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int k = k0 + j < TRACE_PARK_ROWS ? k0 + j : TRACE_PARK_ROWS - 1;
+            slot[j] = park[k * 256];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            g[j] = sc.leaf_geo[k0 + j < n_park ? slot[j] : 0u];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const bool may = leaf_screen(g[j], a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z);
+            pass |= (((k0 + j < n_park) & may) ? 1u : 0u) << (k0 + j);
+          }
+        }
         n_park = 0;
         while (__any(pass != 0)) {
           if (pass != 0) {
-            const int slot = park[(__builtin_ctz(pass)) * 256];
+            const int slot = (int)park[(__builtin_ctz(pass)) * 256];
             pass &= pass - 1;
             if (!(shadow && idx_s >= 0) && leaf(slot)) {
               if (shadow)
@@ -396,42 +445,41 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
 
     if (state == BUSY) {
       // ---- one node visit: the bounds of its (up to four) children ----
-      int next = -1;
-      float next_near = RT_INF;
       bool touch[BVH_WIDTH];
       float near_key[BVH_WIDTH], entry_key[BVH_WIDTH];
       const BvhNode N = sc.bvh[node];
       bvh_visit2(N, qa.x, qa.y, qa.z, ix, iy, iz, ida, bound, touch, near_key, entry_key);
+      uint32_t e[BVH_WIDTH];
 #pragma unroll
       for (int c = 0; c < BVH_WIDTH; c++) {
         const int32_t link = N.link[c];
-        if (touch[c] && link < 0) {
-          // a touched leaf is parked (or, with every slot taken, tested now)
-          const int slot = (~link) >> 3;
-          if (n_park < PARK_SLOTS) {
-            park[n_park++ * 256] = slot;
-          } else if (leaf(slot)) {
-            if (!shadow)
-              bound = fminf(bound, len_s);
-          }
-        } else if (touch[c]) {
-          // shadow: the child entered first; else the child nearest to the world
-          // origin (it tightens `bound`); the others go on the lane's stack
-          const float key = shadow ? entry_key[c] : near_key[c];
-          int push = link;
-          if (key < next_near) {
-            push = next;
-            next = link;
-            next_near = key;
-          }
-          if (push >= 0)
-            stack_l.push(sp, push);
-        }
+        // a touched leaf is parked
+        park[n_park * 256] = (uint32_t)(~link) >> 3;
+        n_park += (touch[c] && link < 0) ? 1 : 0;
+        // a touched inner child becomes (key, node): shadow rays go first to the
+        // child entered first (the nearer an occluder is to the origin, the sooner
+        // the walk ends), the others to the child nearest to the world origin (it
+        // tightens `bound` soonest); 16 bits of either are plenty for an order
+        const uint32_t nk = (c & 1) ? (N.near_bits[c >> 1] & 0xffff0000u) : (N.near_bits[c >> 1] << 16);
+        const uint32_t ek = __float_as_uint(fmaxf(entry_key[c], 0.f)) & 0xffff0000u;
+        e[c] = (touch[c] && link >= 0) ? ((shadow ? ek : nk) | (uint32_t)link) : 0xffffffffu;
       }
-      if (next < 0 && sp > 0)
-        next = stack_l.pop(sp);
-      if (next >= 0 && !(shadow && idx_s >= 0))
-        node = next;
+      order2(e[0], e[1]);
+      order2(e[2], e[3]);
+      order2(e[0], e[2]);
+      order2(e[1], e[3]);
+      order2(e[1], e[2]);
+      // the farthest goes on the stack first, the nearest is visited next
+#pragma unroll
+      for (int c = BVH_WIDTH - 1; c >= 1; c--) {
+        stack_l[sp * 256] = e[c];
+        sp += e[c] != 0xffffffffu ? 1 : 0;
+      }
+      uint32_t next = e[0];
+      if (next == 0xffffffffu && sp > 0)
+        next = stack_l[--sp * 256];
+      if (next != 0xffffffffu)
+        node = (int)(next & 0xffffu);
       else
         state = DRAIN;
     }

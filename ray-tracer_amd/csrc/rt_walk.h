@@ -94,13 +94,16 @@ constexpr int PARK_SLOTS = 8; // parked leaves per lane (rt_walk.h, k_walk)
 // The discriminant screen of maths.cpp:132-133 for leaf slot `slot`: can the
 // exact test pass at all?  (The same b, c, products and comparison as
 // sphere_exact; a lane whose screen fails need not run the rest.)
-__device__ __forceinline__ bool leaf_screen(const SceneDev &sc, int slot, float a4, float ox,
-                                            float oy, float oz, float dx, float dy, float dz) {
-  const float4 g = sc.leaf_geo[slot];
+__device__ __forceinline__ bool leaf_screen(float4 g, float a4, float ox, float oy, float oz,
+                                            float dx, float dy, float dz) {
   const float Lx = ox - g.x, Ly = oy - g.y, Lz = oz - g.z;
   const float b = 2.0f * dot3(dx, dy, dz, Lx, Ly, Lz);
   const float c = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - g.w;
   return !(b * b < a4 * c);
+}
+__device__ __forceinline__ bool leaf_screen(const SceneDev &sc, int slot, float a4, float ox,
+                                            float oy, float oz, float dx, float dy, float dz) {
+  return leaf_screen(sc.leaf_geo[slot], a4, ox, oy, oz, dx, dy, dz);
 }
 
 // k_walk — each lane walks one hierarchy (TRI: the triangles', else the
