@@ -213,6 +213,23 @@ __device__ __forceinline__ void order2(uint32_t &a, uint32_t &b) {
   b = hi;
 }
 
+#ifdef RT_STAMPS
+// Diagnostic build only (make stamps): where a wave of k_trace spends its cycles.
+// [0] wave cycles, then cycles in [1] node visits, [2] parked leaves, [3] handing in,
+// [4] shading (with saving and restoring the walks), [5] fetching; counts of
+// [6] visits, [7] service phases, [8] batches of four screens, [9] rounds of exact
+// leaf tests, [10] batches shaded, [12] waves, [13] service phases forced by a
+// lane's full row of parked leaves; lanes summed over [11] the visits (lanes
+// walking), [14] the exact-test rounds (lanes testing), [15] the screen batches
+// (lanes with a parked leaf in the batch)
+__device__ unsigned long long g_tstamps[16];
+#define RT_TSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RT_TCOUNT(k, v) tst[k] += (v)
+#else
+#define RT_TSTAMP(var)
+#define RT_TCOUNT(k, v)
+#endif
+
 // k_trace — see the head of this file.  Grid: any number of 256-thread blocks;
 // wave w of the grid owns stack[w * stack_cap ...] and hits[w * hit_cap ...].
 __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
@@ -246,54 +263,82 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   uint32_t n_rays = 0;
   bool drained = false; // the frame's queue has nothing left for this block
 
-  auto leaf = [&](int slot) -> bool {
-    return leaf_test(sc, slot, a, a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, len_s, idx_s, sPx, sPy,
-                     sPz);
-  };
+#ifdef RT_STAMPS
+  unsigned long long tst[16] = {};
+#endif
+  RT_TSTAMP(t_begin);
 
   while (true) {
     const int n_free = __builtin_popcountll(__ballot(state != BUSY));
     const bool more = sp_w > 0 || !drained;
     if (n_free == 64 || (more && n_free >= t.fetch_at) ||
         __any(state == BUSY && n_park > TRACE_PARK_FULL)) {
+      RT_TSTAMP(t_s0);
+      RT_TCOUNT(7, 1);
+      RT_TCOUNT(13, (n_free == 64 || (more && n_free >= t.fetch_at)) ? 0 : 1);
       // ---- work off parked leaves, all lanes together: the cheap screen on every
       // parked leaf first, then the full test only as often as the busiest lane
       // has passers ----
       {
-        // four parked leaves at a time: their rows, then their records, then the
-        // arithmetic, so that a lane waits once per four leaves and not twice per leaf
-        unsigned pass = 0;
+        // Four parked leaves at a time: their rows, then their records and indices,
+        // then the arithmetic, so that a lane waits once per four leaves.  Every leaf
+        // gets the discriminant screen of maths.cpp:132-133 (most fail it); the rest
+        // of the test runs, on the same b and c, only while some lane has a passer.
+        // A passer with c > 0 and b > eps is dropped as well: maths.cpp:136-152 then
+        // computes q < 0 and two roots <= 0 (or, with discr == 0, -0.5 b / a < 0) and
+        // reports no hit.
         for (int k0 = 0; __any(k0 < n_park); k0 += 4) {
+          RT_TCOUNT(8, 1);
+          RT_TCOUNT(15, __builtin_popcountll(__ballot(k0 < n_park)));
           uint32_t slot[4];
           float4 g[4];
+          int id[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int k = k0 + j < TRACE_PARK_ROWS ? k0 + j : TRACE_PARK_ROWS - 1;
             slot[j] = park[k * 256];
           }
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            g[j] = sc.leaf_geo[k0 + j < n_park ? slot[j] : 0u];
+          for (int j = 0; j < 4; j++) {
+            slot[j] = k0 + j < n_park ? slot[j] : 0u;
+            g[j] = sc.leaf_geo[slot[j]];
+            id[j] = sc.leaf_idx[slot[j]];
+          }
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const bool may = leaf_screen(g[j], a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z);
-            pass |= (((k0 + j < n_park) & may) ? 1u : 0u) << (k0 + j);
-          }
-        }
-        n_park = 0;
-        while (__any(pass != 0)) {
-          if (pass != 0) {
-            const int slot = (int)park[(__builtin_ctz(pass)) * 256];
-            pass &= pass - 1;
-            if (!(shadow && idx_s >= 0) && leaf(slot)) {
-              if (shadow)
-                state = DRAIN; // occluded: nothing more to find
-              else
-                bound = fminf(bound, len_s);
+            const float Lx = qa.x - g[j].x, Ly = qa.y - g[j].y, Lz = qa.z - g[j].z; // maths.cpp:126
+            const float b = 2.0f * dot3(qb.x, qb.y, qb.z, Lx, Ly, Lz);               // :128
+            const float c = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - g[j].w;                   // :129
+            const float bb = b * b, ac = a4 * c;                                     // :132
+            const bool may = (k0 + j < n_park) & !(bb < ac) & !((c > 0.f) & (b > 0.001f)) &
+                             !(shadow & (idx_s >= 0));
+            if (__any(may)) {
+              RT_TCOUNT(9, 1);
+              RT_TCOUNT(14, __builtin_popcountll(__ballot(may)));
+              float Px, Py, Pz;
+              if (may && sphere_finish(a, b, c, bb, ac, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, Px, Py,
+                                       Pz)) {
+                const float len = length3(Px, Py, Pz);
+                // smallest |P|, lowest index on ties (renderer.cpp:168-177, order-free)
+                if (len < RT_INF && (len < len_s || (len == len_s && id[j] < idx_s))) {
+                  len_s = len;
+                  idx_s = id[j];
+                  sPx = Px;
+                  sPy = Py;
+                  sPz = Pz;
+                  if (shadow)
+                    state = DRAIN; // occluded: nothing more to find
+                  else
+                    bound = fminf(bound, len);
+                }
+              }
             }
           }
         }
+        n_park = 0;
       }
+      RT_TSTAMP(t_s1);
+      RT_TCOUNT(2, t_s1 - t_s0);
       // ---- hand in finished items ----
       {
         const bool done = state == DRAIN;
@@ -312,6 +357,8 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
         if (done)
           state = EMPTY;
       }
+      RT_TSTAMP(t_s2);
+      RT_TCOUNT(3, t_s2 - t_s1);
       // ---- shade the waiting hits, 64 at a time (the last few when nothing else is left) ----
       if (n_hits >= 64 || (n_hits > 0 && sp_w == 0 && drained)) {
         // walks in progress step aside: their state goes to the wave's save area
@@ -325,6 +372,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
         while (n_hits >= 64 || (n_hits > 0 && sp_w == 0 && drained)) {
           const uint32_t n = n_hits < 64 ? n_hits : 64;
           n_hits -= n;
+          RT_TCOUNT(10, 1);
           const ShadeResult r =
               trace_shade(sc, stack, sp_w, t.stack_cap, t.overflow, hits, n_hits, n, t.max_depth);
           sp_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.sp);
@@ -360,6 +408,8 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           ida = wr.ida;
         }
       }
+      RT_TSTAMP(t_s3);
+      RT_TCOUNT(4, t_s3 - t_s2);
       // ---- fetch: the wave's own stack first, then the frame's queue ----
       {
         unsigned long long e = __ballot(state == EMPTY);
@@ -438,10 +488,17 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           }
         }
       }
+#ifdef RT_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tst[5] += __builtin_amdgcn_s_memtime() - t_s3;
+#endif
       if (!__any(state != EMPTY) && sp_w == 0 && n_hits == 0 && drained)
         break;
       continue;
     }
+    RT_TSTAMP(t_v0);
+    RT_TCOUNT(6, 1);
+    RT_TCOUNT(11, __builtin_popcountll(__ballot(state == BUSY)));
 
     if (state == BUSY) {
       // ---- one node visit: the bounds of its (up to four) children ----
@@ -483,7 +540,17 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
       else
         state = DRAIN;
     }
+#ifdef RT_STAMPS
+    tst[1] += __builtin_amdgcn_s_memtime() - t_v0;
+#endif
   }
+#ifdef RT_STAMPS
+  tst[0] = __builtin_amdgcn_s_memtime() - t_begin;
+  tst[12] = 1;
+  if (lane == 0)
+    for (int k = 0; k < 16; k++)
+      atomicAdd(&g_tstamps[k], tst[k]);
+#endif
   add_ray_count(t.ray_count, n_rays);
 }
 
