@@ -632,9 +632,10 @@ extern "C" int rt_debug_stamps(unsigned long long *out16) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 // The same for the stamp counters of k_trace (rt_trace.h).
-extern "C" int rt_debug_trace_stamps(unsigned long long *out16) {
-  unsigned long long zero[16] = {};
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tstamps), sizeof zero) != hipSuccess)
+extern "C" int rt_debug_trace_stamps(unsigned long long *out24) {
+  unsigned long long zero[24] = {};
+  zero[19] = ~0ull; // a minimum
+  if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_tstamps), sizeof zero) != hipSuccess)
     return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_tstamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }

@@ -37,6 +37,10 @@ namespace rt {
 // The sign bit of the fourth word tells them apart (a weight is positive, a pixel
 // index is below 2^26).
 #define RT_ITEM_SHADOW 0x80000000u
+// a block that has used up a segment of the frame's queue goes on to the segment
+// this many further (odd, so that every segment is reached)
+constexpr uint32_t QUEUE_HOP = 37;
+static_assert(QUEUE_SEGMENTS % 2 == 0 && QUEUE_HOP % 2 == 1, "the hops must reach every segment");
 
 // The wave's stack of items: push for the lanes with `want`, consecutive slots in
 // lane order.  Returns the new height.  An item that does not fit is dropped
@@ -182,7 +186,8 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
 // Word (row * 256 + thread): the 64 lanes of a wave hit 64 different banks whatever
 // row each of them is at.  Rows 0 .. TRACE_STACK_ROWS-1 are the lane's stack of
 // nodes still to visit, the next TRACE_PARK_ROWS its parked leaves; five blocks of
-// 32 KB fill a CU's LDS.  A walk stacks at most three siblings per level of inner
+// 31 KB share a CU's LDS (of five blocks of 32 KB the hardware runs only four).
+// A walk stacks at most three siblings per level of inner
 // nodes below which there are inner nodes (and one row more takes the stores that
 // do not count), so TRACE_STACK_ROWS rows serve trees of up to
 // TRACE_MAX_TREE_DEPTH levels of inner nodes (65 536 spheres when balanced);
@@ -200,11 +205,12 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
 // never enters a visit with more than TRACE_PARK_FULL parked leaves: the wave works
 // the parked leaves off first (all lanes together, as at every refill).
 constexpr int TRACE_STACK_ROWS = 22;
-constexpr int TRACE_PARK_ROWS = 10;
+constexpr int TRACE_PARK_ROWS = 9;
 constexpr int TRACE_PARK_FULL = TRACE_PARK_ROWS - BVH_WIDTH;
 static_assert(3 * (TRACE_MAX_TREE_DEPTH - 1) + 1 <= TRACE_STACK_ROWS,
               "three rows per level but the last, and the row the stores that do not count land in");
-static_assert((TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 1024 <= 32768, "five blocks per CU");
+static_assert((TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 1024 < 32768,
+              "five blocks per CU: five times 32 KB, all of a CU's LDS, are not admitted");
 
 // Sorts two packed entries: a <= b afterwards.
 __device__ __forceinline__ void order2(uint32_t &a, uint32_t &b) {
@@ -221,8 +227,10 @@ __device__ __forceinline__ void order2(uint32_t &a, uint32_t &b) {
 // leaf tests, [10] batches shaded, [12] waves, [13] service phases forced by a
 // lane's full row of parked leaves; lanes summed over [11] the visits (lanes
 // walking), [14] the exact-test rounds (lanes testing), [15] the screen batches
-// (lanes with a parked leaf in the batch)
-__device__ unsigned long long g_tstamps[16];
+// (lanes with a parked leaf in the batch); [16] the longest wave's cycles; [17] the
+// end time of the last wave and [18] the sum of the waves' end times, both in
+// cycles after the first wave's start ([19])
+__device__ unsigned long long g_tstamps[24];
 #define RT_TSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define RT_TCOUNT(k, v) tst[k] += (v)
 #else
@@ -234,12 +242,19 @@ __device__ unsigned long long g_tstamps[16];
 // wave w of the grid owns stack[w * stack_cap ...] and hits[w * hit_cap ...].
 __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   const int lane = threadIdx.x & 63;
-  const uint32_t seg = my_segment();
+  // The block starts on segment (block % QUEUE_SEGMENTS) of the frame's queue and
+  // moves on to the other segments when that one is used up (any wave may take
+  // from any segment: the cursors are atomics, the lengths were written by
+  // k_render before this launch).  Without this a wave whose segment held little
+  // or cheap work is done long before the others: the mean wave lived 70 % of the
+  // longest one.
+  uint32_t seg = my_segment();
+  uint32_t segs_left = QUEUE_SEGMENTS - 1;
   uint32_t n_in = t.in.count[seg * CTL_WORDS];
   if (n_in > t.in.seg_capacity)
     n_in = t.in.seg_capacity;
-  const size_t seg_base = (size_t)seg * t.in.seg_capacity;
-  uint32_t *const cursor = t.cursor + seg * CTL_WORDS;
+  size_t seg_base = (size_t)seg * t.in.seg_capacity;
+  uint32_t *cursor = t.cursor + seg * CTL_WORDS;
   const size_t wave_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   float4 *const stack = t.stack + 2 * wave_id * t.stack_cap;
   float4 *const hits = t.hits + 3 * wave_id * t.hit_cap;
@@ -434,14 +449,27 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           if (lane == leader)
             base = atomicAdd(cursor, (uint32_t)n_e);
           base = __builtin_amdgcn_readlane(base, leader);
-          if (base + (uint32_t)n_e >= n_in)
-            drained = true;
           if (state == EMPTY && !got) {
             const uint32_t r = base + (uint32_t)__builtin_popcountll(e & ((1ull << lane) - 1ull));
             if (r < n_in) {
               qa = t.in.items[2 * (seg_base + r)];
               qb = t.in.items[2 * (seg_base + r) + 1];
               got = true;
+            }
+          }
+          if (base + (uint32_t)n_e >= n_in) {
+            // this segment is used up: on to the next one (lanes it could not
+            // serve are served at the next refill), or nothing is left
+            if (segs_left == 0) {
+              drained = true;
+            } else {
+              segs_left--;
+              seg = (seg + QUEUE_HOP) % QUEUE_SEGMENTS;
+              n_in = t.in.count[seg * CTL_WORDS];
+              if (n_in > t.in.seg_capacity)
+                n_in = t.in.seg_capacity;
+              seg_base = (size_t)seg * t.in.seg_capacity;
+              cursor = t.cursor + seg * CTL_WORDS;
             }
           }
         }
@@ -545,11 +573,19 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
 #endif
   }
 #ifdef RT_STAMPS
-  tst[0] = __builtin_amdgcn_s_memtime() - t_begin;
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+  tst[0] = t_end - t_begin;
   tst[12] = 1;
-  if (lane == 0)
+  if (lane == 0) {
     for (int k = 0; k < 16; k++)
       atomicAdd(&g_tstamps[k], tst[k]);
+    atomicMax(&g_tstamps[16], tst[0]);
+    atomicMax(&g_tstamps[17], t_end);
+    atomicAdd(&g_tstamps[18], t_end & 0xffffffffffull);
+    atomicMin(&g_tstamps[19], t_begin);
+    atomicAdd(&g_tstamps[20], tst[6] == 0 ? 1ull : 0ull);            // waves that never visited a node
+    atomicAdd(&g_tstamps[21], tst[0] * 2 < 20000000ull ? 1ull : 0ull); // waves under 10 M cycles
+  }
 #endif
   add_ray_count(t.ray_count, n_rays);
 }

@@ -16,10 +16,10 @@ sc, w, h, depth = bench.build_scene(name)
 dev = torch.device("cuda", 0)
 fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
 L = rtamd.lib()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 with rtamd.DeviceScene(sc) as ds:
     ds.set_one_launch(True)
-    for k in range(3):
+    for k in range(4):
         ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth)
         torch.cuda.synchronize()
         L.rt_debug_trace_stamps(out)
@@ -36,3 +36,8 @@ print(f"per service phase: {v[8] / max(1, v[7]):.2f} screen batches ({v[15] / ma
       f"{v[10] / max(1, v[7]):.2f} batches shaded")
 print(f"cycles per service phase: leaves {v[2] / max(1, v[7]):.0f}, hand-in {v[3] / max(1, v[7]):.0f}, "
       f"shading {v[4] / max(1, v[7]):.0f} ({v[4] / max(1, v[10]):.0f} per batch), fetch {v[5] / max(1, v[7]):.0f}")
+first, last = v[19], v[17]
+mean_end = (v[18] / wv) - (int(first) & 0xffffffffff)
+print(f"longest wave {v[16]:.0f} cycles; last wave ends {last - first:.0f} cycles after the first one starts, "
+      f"the mean wave at {mean_end:.0f} ({100 * mean_end / max(1.0, last - first):.0f} % of that)")
+print(f"waves that never visited a node: {v[20]:.0f}; waves that lived under 10 M cycles: {v[21]:.0f}")
