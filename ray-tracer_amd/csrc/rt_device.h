@@ -462,22 +462,34 @@ __device__ __forceinline__ void bvh_visit2(const BvhNode &N, float ox, float oy,
                    fmaxf(fabsf(bz), fabsf(gz));
   const float m = S1 * 0.0021f, mu = S1 * 0.0045f;
   const float Ux = ux * ix, Uy = uy * iy, Uz = uz * iz;
-  const float Alx = (bx - m) * ix, Ahx = (bx + m) * ix;
-  const float Aly = (by - m) * iy, Ahy = (by + m) * iy;
-  const float Alz = (bz - m) * iz, Ahz = (bz + m) * iz;
+  // Per axis the line enters through the low face when it runs upwards and through
+  // the high face otherwise (i is never zero: capped_inverse), so the faces are
+  // picked by the sign of i once per node instead of by a min and a max per child:
+  // with s = m carrying the sign of i, An = ((org - o) - s) * i belongs to the
+  // entry face and Af = ((org - o) + s) * i to the exit face, the same numbers as
+  // A_lo and A_hi above.  fma is monotonic in each argument, so t_n <= t_f
+  // wherever the box is not inverted.
+  const bool upx = ix >= 0.f, upy = iy >= 0.f, upz = iz >= 0.f;
+  const float sx = copysignf(m, ix), sy = copysignf(m, iy), sz = copysignf(m, iz);
+  const float Anx = (bx - sx) * ix, Afx = (bx + sx) * ix;
+  const float Any = (by - sy) * iy, Afy = (by + sy) * iy;
+  const float Anz = (bz - sz) * iz, Afz = (bz + sz) * iz;
+  const uint32_t qnx = upx ? N.qlo[0] : N.qhi[0], qfx = upx ? N.qhi[0] : N.qlo[0];
+  const uint32_t qny = upy ? N.qlo[1] : N.qhi[1], qfy = upy ? N.qhi[1] : N.qlo[1];
+  const uint32_t qnz = upz ? N.qlo[2] : N.qhi[2], qfz = upz ? N.qhi[2] : N.qlo[2];
   const float behind_below = -(mu * ida);
   const float far_above = bound + mu;
 #pragma unroll
   for (int c = 0; c < BVH_WIDTH; c++) {
     const int sh = 8 * c;
-    const float tlx = fmaf((float)((N.qlo[0] >> sh) & 0xffu), Ux, Alx);
-    const float tly = fmaf((float)((N.qlo[1] >> sh) & 0xffu), Uy, Aly);
-    const float tlz = fmaf((float)((N.qlo[2] >> sh) & 0xffu), Uz, Alz);
-    const float thx = fmaf((float)((N.qhi[0] >> sh) & 0xffu), Ux, Ahx);
-    const float thy = fmaf((float)((N.qhi[1] >> sh) & 0xffu), Uy, Ahy);
-    const float thz = fmaf((float)((N.qhi[2] >> sh) & 0xffu), Uz, Ahz);
-    const float tmin = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fminf(tlz, thz));
-    const float tmax = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
+    const float tnx = fmaf((float)((qnx >> sh) & 0xffu), Ux, Anx);
+    const float tny = fmaf((float)((qny >> sh) & 0xffu), Uy, Any);
+    const float tnz = fmaf((float)((qnz >> sh) & 0xffu), Uz, Anz);
+    const float tfx = fmaf((float)((qfx >> sh) & 0xffu), Ux, Afx);
+    const float tfy = fmaf((float)((qfy >> sh) & 0xffu), Uy, Afy);
+    const float tfz = fmaf((float)((qfz >> sh) & 0xffu), Uz, Afz);
+    const float tmin = fmaxf(fmaxf(tnx, tny), tnz);
+    const float tmax = fminf(fminf(tfx, tfy), tfz);
     const bool miss = (tmin - tmax) > 9.5367431640625e-07f * (fabsf(tmin) + fabsf(tmax));
     const bool behind = tmax < behind_below;
     const float near = bvh_near(N.near_bits, c);

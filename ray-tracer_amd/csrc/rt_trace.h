@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           }
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            slot[j] = k0 + j < n_park ? slot[j] : 0u;
+            slot[j] = k0 + j < n_park ? (~slot[j]) >> 3 : 0u;
             g[j] = sc.leaf_geo[slot[j]];
             id[j] = sc.leaf_idx[slot[j]];
           }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
       for (int c = 0; c < BVH_WIDTH; c++) {
         const int32_t link = N.link[c];
         // a touched leaf is parked
-        park[n_park * 256] = (uint32_t)(~link) >> 3;
+        park[n_park * 256] = (uint32_t)link; // the leaf's slot is (~link) >> 3
         n_park += (touch[c] && link < 0) ? 1 : 0;
         // a touched inner child becomes (key, node): shadow rays go first to the
         // child entered first (the nearer an occluder is to the origin, the sooner
