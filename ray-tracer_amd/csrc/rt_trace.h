@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   bool drained = false; // the frame's queue has nothing left for this block
 
 #ifdef RT_STAMPS
-  unsigned long long tst[16] = {};
+  unsigned long long tst[24] = {};
+  float dbg_near = 0.f;
 #endif
   RT_TSTAMP(t_begin);
 
@@ -527,6 +528,10 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
     RT_TSTAMP(t_v0);
     RT_TCOUNT(6, 1);
     RT_TCOUNT(11, __builtin_popcountll(__ballot(state == BUSY)));
+#ifdef RT_STAMPS
+    tst[22] += __builtin_popcountll(__ballot(state == BUSY && !shadow));
+    tst[23] += __builtin_popcountll(__ballot(state == BUSY && !shadow && dbg_near > bound * 1.01f + 0.01f));
+#endif
 
     if (state == BUSY) {
       // ---- one node visit: the bounds of its (up to four) children ----
@@ -563,6 +568,9 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
       uint32_t next = e[0];
       if (next == 0xffffffffu && sp > 0)
         next = stack_l[--sp * 256];
+#ifdef RT_STAMPS
+      dbg_near = __uint_as_float(next & 0xffff0000u);
+#endif
       if (next != 0xffffffffu)
         node = (int)(next & 0xffffu);
       else
@@ -583,6 +591,8 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
     atomicMax(&g_tstamps[17], t_end);
     atomicAdd(&g_tstamps[18], t_end & 0xffffffffffull);
     atomicMin(&g_tstamps[19], t_begin);
+    atomicAdd(&g_tstamps[22], tst[22]);
+    atomicAdd(&g_tstamps[23], tst[23]);
     atomicAdd(&g_tstamps[20], tst[6] == 0 ? 1ull : 0ull);            // waves that never visited a node
     atomicAdd(&g_tstamps[21], tst[0] * 2 < 20000000ull ? 1ull : 0ull); // waves under 10 M cycles
   }

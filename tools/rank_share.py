@@ -41,5 +41,10 @@ with rtamd.DeviceScene(sc) as ds:
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) / k * 1e3
         base = base or ms
+        ds.time_kernels(True)
+        frame()
+        st = ds.kernel_times()
+        ds.time_kernels(False)
         print(f"N={n}: one rank's share {ms:.3f} ms per frame -> compute-only scaling efficiency "
-              f"{base / (n * ms):.2f}", flush=True)
+              f"{base / (n * ms):.2f}   (primary {st[0]:.3f}, bounce levels {st[1]:.3f}, "
+              f"final sum {st[2]:.3f} ms)", flush=True)

@@ -41,3 +41,4 @@ mean_end = (v[18] / wv) - (int(first) & 0xffffffffff)
 print(f"longest wave {v[16]:.0f} cycles; last wave ends {last - first:.0f} cycles after the first one starts, "
       f"the mean wave at {mean_end:.0f} ({100 * mean_end / max(1.0, last - first):.0f} % of that)")
 print(f"waves that never visited a node: {v[20]:.0f}; waves that lived under 10 M cycles: {v[21]:.0f}")
+print(f"lane-visits of nearest-hit rays: {v[22]:.0f}, of which into a node already beyond the best hit: {v[23]:.0f} ({100 * v[23] / max(1.0, v[22]):.1f} %)")
