@@ -255,6 +255,7 @@ struct rt_scene {
     d.bvh = use_bvh ? bvh.p : nullptr;
     d.leaf_geo = use_bvh ? leaf_geo.p : nullptr;
     d.leaf_idx = use_bvh ? leaf_idx.p : nullptr;
+    d.bvh_lds = use_bvh && bvh_depth <= rt::LDS_WALK_MAX_DEPTH && bvh_nodes <= rt::LDS_WALK_MAX_NODES;
     const bool use_tbvh = has_tbvh && screen != 0;
     d.tbvh = use_tbvh ? tbvh.p : nullptr;
     d.tleaf = use_tbvh ? tleaf.p : nullptr;
@@ -449,13 +450,17 @@ int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
 
 // Does a frame of this scene run its bounce levels as one launch (rt_trace.h)?
 // That kernel walks the sphere hierarchy (a lane's stack of nodes in LDS, sized
-// for trees of TRACE_MAX_TREE_DEPTH levels) and loops over the triangles; scenes
+// for trees of LDS_WALK_MAX_DEPTH levels) and loops over the triangles; scenes
 // with a triangle hierarchy, scenes without any hierarchy or with a deeper one,
 // more lights than one group, and the largest queue setting (which must not be
 // able to overflow) take the launch-per-level path.
+bool bvh_fits_lds(const rt_scene *S) {
+  return S->has_bvh && S->bvh_depth <= rt::LDS_WALK_MAX_DEPTH &&
+         S->bvh_nodes <= rt::LDS_WALK_MAX_NODES;
+}
 bool uses_trace(const rt_scene *S) {
   return S->has_bvh && S->screen != 0 && !S->has_tbvh && S->l_size <= kLightGroup &&
-         S->bvh_depth <= rt::TRACE_MAX_TREE_DEPTH && S->bvh_nodes <= rt::TRACE_MAX_NODES &&
+         bvh_fits_lds(S) &&
          S->rays_per_pixel < 256 && S->one_launch;
 }
 

@@ -51,6 +51,7 @@ struct SceneDev {
   const BvhNode *bvh;
   const float4 *leaf_geo;    // sph_geo gathered into leaf order
   const int32_t *leaf_idx;   // original sphere index of each leaf slot
+  int bvh_lds;               // the tree fits a lane's LDS stack (LDS_STACK_ROWS)
   // hierarchy over the triangles (rt_tribvh.h); tbvh == nullptr: none, loop
   const TriNode *tbvh;
   const TriLeaf *tleaf;      // the triangles in leaf order, with their indices
@@ -315,34 +316,21 @@ __device__ __forceinline__ bool beam_keeps(const Beam &B, float4 g) {
 // BVH_STACK / 3 levels, so BVH_STACK entries always suffice.
 //
 // Two homes for it.  PrivateStack: an array in private memory (scratch), 192 bytes
-// per lane; costs no LDS, so six blocks of a walk kernel and blocks of other
-// frames' kernels share a CU freely.  LdsStack: the first LDS_STACK entries of
-// every lane in LDS, word (entry * 256 + thread), so the 64 lanes of a wave hit 64
-// different banks whatever their stack heights are; entries beyond that (trees of
-// more than 65 536 leaves) spill to a small private array.  Measured on the
-// 10 000-sphere depth-8 frame: the launch-per-level walks do not care (0.86 ms per
-// level either way, and 24 KB of LDS per block cost them a wave per SIMD and the
-// overlap of frames in flight), the one-launch kernel gains 15 % from LDS
-// (8.6 -> 7.3 ms): its waves also store and load work items, and every scratch
-// write in front of those in the wave's memory queue delays them.
-// Every kernel that walks uses 256-thread blocks.
-constexpr int LDS_STACK = 24;
-constexpr int LDS_STACK_WORDS = LDS_STACK * 256;
-struct LdsStack {
-  int *lds; // this thread's column of the block's LDS array
-  int spill[BVH_STACK - LDS_STACK];
-  __device__ __forceinline__ void push(int &sp, int v) {
-    if (sp < LDS_STACK)
-      lds[sp * 256] = v;
-    else if (sp < BVH_STACK)
-      spill[sp - LDS_STACK] = v;
-    sp += sp < BVH_STACK ? 1 : 0;
-  }
-  __device__ __forceinline__ int pop(int &sp) {
-    --sp;
-    return sp < LDS_STACK ? lds[sp * 256] : spill[sp - LDS_STACK];
-  }
-};
+// per lane, for trees of any admitted depth.  In LDS (kernels of 256 threads): word
+// (row * 256 + thread), so the 64 lanes of a wave hit 64 different banks whatever
+// row each of them is at; LDS_STACK_ROWS rows serve trees of up to
+// LDS_WALK_MAX_DEPTH levels of inner nodes (three rows per level below which there
+// are inner nodes, and one row more that takes the stores that do not count:
+// stack_children), 65 536 spheres when balanced.  An entry is
+// (16 bits of ordering key) << 16 | node index, hence at most 65 535 nodes; the host
+// sets SceneDev::bvh_lds only for such trees.  Scratch stores and loads go through
+// the same queue as the walk's node loads and delay them; the LDS form also lets
+// the visit be written without branches (below).
+constexpr int LDS_STACK_ROWS = 22;
+constexpr int LDS_WALK_MAX_DEPTH = 8;
+constexpr size_t LDS_WALK_MAX_NODES = 65535;
+static_assert(3 * (LDS_WALK_MAX_DEPTH - 1) + 1 <= LDS_STACK_ROWS,
+              "three rows per level but the last, and the row of the stores that do not count");
 struct PrivateStack {
   int slot[BVH_STACK];
   __device__ __forceinline__ void push(int &sp, int v) {
@@ -509,6 +497,54 @@ __device__ __forceinline__ void bvh_visit(const BvhNode &N, float ox, float oy, 
     bvh_visit2(N, ox, oy, oz, ix, iy, iz, ida, bound, touch, other, key);
   else
     bvh_visit2(N, ox, oy, oz, ix, iy, iz, ida, bound, touch, key, other);
+}
+
+// Sorts two packed entries: a <= b afterwards.
+__device__ __forceinline__ void order2(uint32_t &a, uint32_t &b) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+
+constexpr uint32_t NO_ENTRY = 0xffffffffu;
+
+// What a visit does with the touched inner children, written without branches: each
+// becomes an entry (key, node), a five-step network of integer min / max puts the
+// entries in order, the farther ones go on the lane's LDS stack by unconditional
+// stores whose row only advances for a real entry (a store that does not count is
+// overwritten by the next one), and the nearest one, or failing that the top of the
+// stack, is returned (NO_ENTRY: the walk is over).  by_entry: order by the
+// parameter at which the line enters the child (any-hit walks: the nearer an
+// occluder is to the ray's origin, the sooner it ends the walk); otherwise by the
+// child's distance bound from the world origin (it tightens `bound` soonest).
+// Sixteen bits of either are plenty for an order.  The branching form of this, a
+// dozen exec-mask branches per child, was more than half of a visit's instructions.
+__device__ __forceinline__ uint32_t stack_children(const BvhNode &N, const bool touch[BVH_WIDTH],
+                                                   const float entry_key[BVH_WIDTH],
+                                                   bool by_entry, uint32_t *stack_l, int &sp) {
+  uint32_t e[BVH_WIDTH];
+#pragma unroll
+  for (int c = 0; c < BVH_WIDTH; c++) {
+    const int32_t link = N.link[c];
+    const uint32_t nk =
+        (c & 1) ? (N.near_bits[c >> 1] & 0xffff0000u) : (N.near_bits[c >> 1] << 16);
+    const uint32_t ek = __float_as_uint(fmaxf(entry_key[c], 0.f)) & 0xffff0000u;
+    e[c] = (touch[c] && link >= 0) ? ((by_entry ? ek : nk) | (uint32_t)link) : NO_ENTRY;
+  }
+  order2(e[0], e[1]);
+  order2(e[2], e[3]);
+  order2(e[0], e[2]);
+  order2(e[1], e[3]);
+  order2(e[1], e[2]);
+#pragma unroll
+  for (int c = BVH_WIDTH - 1; c >= 1; c--) {
+    stack_l[sp * 256] = e[c];
+    sp += e[c] != NO_ENTRY ? 1 : 0;
+  }
+  uint32_t next = e[0];
+  if (next == NO_ENTRY && sp > 0)
+    next = stack_l[--sp * 256];
+  return next;
 }
 
 // ---- the triangle hierarchy (rt_tribvh.h) ------------------------------------------
@@ -720,12 +756,76 @@ __device__ __forceinline__ void walk_triangles(const SceneDev &sc, float ox, flo
   }
 }
 
+// The sphere walk of one lane's ray with the lane's stack in LDS (stack_l = this
+// thread's column, rows LDS_STACK_ROWS apart by 256 words; sc.bvh_lds must hold).
+// The same visits, exits and order-free nearest-hit rule as the walk with a
+// private stack in trace<> below; the visit itself is branch-free (stack_children)
+// and the touched leaves are tested right away, each lane's next one per round
+// (the rays of a wave that comes here travel together, so the rounds are dense and
+// `bound` is tightened at once).  `bound`: a |P| beyond which a hit cannot matter.
+template <bool ANY_HIT>
+__device__ __forceinline__ void walk_spheres_lds(const SceneDev &sc, uint32_t *stack_l, bool go,
+                                                 float a, float a4, float ox, float oy, float oz,
+                                                 float dx, float dy, float dz, float bound,
+                                                 float &len_s, int &idx_s, float &sPx, float &sPy,
+                                                 float &sPz, unsigned &n_nodes, unsigned &n_leaf) {
+  const SphWalkRay wr = sph_walk_ray(dx, dy, dz, a);
+  int sp = 0, node = 0;
+  while (__any(go)) {
+    if (go) {
+      const BvhNode N = sc.bvh[node];
+      bool touch[BVH_WIDTH];
+      float near_key[BVH_WIDTH], entry_key[BVH_WIDTH];
+      bvh_visit2(N, ox, oy, oz, wr.ix, wr.iy, wr.iz, wr.ida, bound, touch, near_key, entry_key);
+      n_nodes += BVH_WIDTH;
+      const uint32_t next = stack_children(N, touch, entry_key, ANY_HIT, stack_l, sp);
+      unsigned lm = 0;
+#pragma unroll
+      for (int c = 0; c < BVH_WIDTH; c++)
+        lm |= ((touch[c] && N.link[c] < 0) ? 1u : 0u) << c;
+      while (__any(lm != 0)) {
+        if (lm != 0) {
+          const unsigned c = (unsigned)__builtin_ctz(lm);
+          lm &= lm - 1;
+          const int32_t link = c == 0 ? N.link[0] : c == 1 ? N.link[1] : c == 2 ? N.link[2] : N.link[3];
+          const int slot = (~link) >> 3;
+          n_leaf += 1;
+          const float4 g = sc.leaf_geo[slot];
+          const int idx = sc.leaf_idx[slot];
+          float Px, Py, Pz;
+          if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
+            const float len = length3(Px, Py, Pz);
+            // renderer.cpp:170 scans in index order with a strict '>': the smallest
+            // |P| wins and, among equals, the lowest index
+            if (len < RT_INF && (len < len_s || (len == len_s && idx < idx_s))) {
+              len_s = len;
+              idx_s = idx;
+              sPx = Px;
+              sPy = Py;
+              sPz = Pz;
+              if (ANY_HIT)
+                lm = 0;
+              else
+                bound = fminf(bound, len);
+            }
+          }
+        }
+      }
+      if (next != NO_ENTRY && !(ANY_HIT && idx_s >= 0))
+        node = (int)(next & 0xffffu);
+      else
+        go = false;
+    }
+  }
+}
+
 template <bool FROM_EYE, bool ANY_HIT, int BEAM, bool VERIFY = false>
 __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                                      float oy, float oz, float dx, float dy,
                                      float dz, float Xx = 0.f, float Xy = 0.f,
                                      float Xz = 0.f, float Dk = 0.f,
-                                     ScreenStats st = ScreenStats{nullptr, nullptr, nullptr}) {
+                                     ScreenStats st = ScreenStats{nullptr, nullptr, nullptr},
+                                     uint32_t *lds_stack = nullptr) {
   float len_t = RT_INF, len_s = RT_INF;
   int idx_t = -1, idx_s = -1;
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
@@ -832,7 +932,19 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
     const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;
     if (!__any(seek && a > 0.f && !sane)) {
       screened = true;
-      if (seek && a > 0.f) {
+      if (lds_stack != nullptr && sc.bvh_lds) {
+        // a sphere can only win against the nearest triangle by being strictly
+        // nearer (renderer.cpp:181)
+        unsigned n_nodes = 0, n_leaf = 0;
+        walk_spheres_lds<ANY_HIT>(sc, lds_stack, seek && a > 0.f, a, a4, ox, oy, oz, dx, dy, dz,
+                                  ANY_HIT ? RT_INF : len_t, len_s, idx_s, sPx, sPy, sPz, n_nodes,
+                                  n_leaf);
+        if (VERIFY && st.walk && seek && a > 0.f) {
+          atomicAdd(st.walk + 0, 1ull);
+          atomicAdd(st.walk + 1, (unsigned long long)n_nodes);
+          atomicAdd(st.walk + 2, (unsigned long long)n_leaf);
+        }
+      } else if (seek && a > 0.f) {
         PrivateStack stack;
         int sp = 0;
         int node = 0;

@@ -100,10 +100,6 @@ struct TraceArgs {
   int fetch_at;       // refill a wave when this many of its lanes have nothing to do
 };
 constexpr uint32_t TRACE_SAVE_WORDS = 20;
-// k_trace keeps a lane's stack of nodes in LDS: trees of at most this many levels
-// of inner nodes and at most this many nodes (rt_trace.h)
-constexpr int TRACE_MAX_TREE_DEPTH = 8;
-constexpr size_t TRACE_MAX_NODES = 65535;
 constexpr uint32_t TRACE_HIT_CAP = 128; // < 64 waiting + <= 64 handed in at once
 
 struct ShadeArgs {

@@ -262,7 +262,8 @@ template <bool PRIMARY, bool MATERIALS, int BEAM, bool VERIFY>
 __device__ __forceinline__ uint32_t
 shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
            float dx, float dy, float dz, float w, uint32_t pixel, uint32_t depth,
-           uint32_t &fb0, uint32_t &fb1, uint32_t &fb2, ScreenStats st) {
+           uint32_t &fb0, uint32_t &fb1, uint32_t &fb2, ScreenStats st,
+           uint32_t *lds_stack = nullptr) {
   uint32_t n_rays = 0;
   if (!__any(hit))
     return 0;
@@ -292,7 +293,7 @@ shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
       // shadow rays of the wave aim at the light: that is the beam's apex.
       Hit sh = trace<false, true, BEAM, VERIFY>(sc, lit, h.Px, h.Py, h.Pz, lx, ly,
                                                 lz, light.x, light.y, light.z,
-                                                dist, st);
+                                                dist, st, lds_stack);
       if (lit) {
         n_rays++;
         if (sh.kind == 0) {
@@ -379,8 +380,11 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
   normalize3(dx, dy, dz);
 
   constexpr int BM = ACCEL;
+  // the lanes' stacks of the sphere walk (rt_device.h, walk_spheres_lds)
+  __shared__ uint32_t walk_words[ACCEL == RT_ACCEL_BVH ? LDS_STACK_ROWS * 256 : 1];
+  uint32_t *const lds_stack = ACCEL == RT_ACCEL_BVH ? walk_words + threadIdx.x : nullptr;
   Hit h = trace<true, false, BM, VERIFY>(sc, inside, cam.ox, cam.oy, cam.oz, dx,
-                                         dy, dz, cam.ox, cam.oy, cam.oz, 0.f, st);
+                                         dy, dz, cam.ox, cam.oy, cam.oz, 0.f, st, lds_stack);
 
   uint32_t fb0 = 0, fb1 = 0, fb2 = 0; // renderer.cpp:50-52
   uint32_t n_rays = inside ? 1u : 0u;
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
     }
   } else {
     n_rays += shade_hits<true, MATERIALS, BM, VERIFY>(sc, bd, hit, h, dx, dy, dz, 1.0f,
-                                                      (uint32_t)p, 1u, fb0, fb1, fb2, st);
+                                                      (uint32_t)p, 1u, fb0, fb1, fb2, st,
+                                                      lds_stack);
   }
 
   if (inside) {
@@ -434,6 +439,8 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
   // lane walks the sphere hierarchy for its own ray, shadow rays included.
   constexpr int BM = BEAM ? RT_ACCEL_BVH : RT_BEAM_NONE;
   constexpr int BS = BEAM ? RT_ACCEL_BVH : RT_BEAM_NONE;
+  __shared__ uint32_t walk_words[BEAM ? LDS_STACK_ROWS * 256 : 1];
+  uint32_t *const lds_stack = BEAM ? walk_words + threadIdx.x : nullptr;
   uint32_t n_rays = 0;
   for (uint32_t base = first; base < n_in; base += stride) {
     const uint32_t r = base + (threadIdx.x & 63);
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
     const uint32_t tag = __float_as_uint(b.w);
     const uint32_t pixel = tag >> 6, depth = tag & 63u;
     Hit h = trace<false, false, BM, VERIFY>(sc, live, a.x, a.y, a.z, b.x, b.y, b.z, 0.f,
-                                            0.f, 0.f, 0.f, st);
+                                            0.f, 0.f, 0.f, st, lds_stack);
     if (live)
       n_rays++;
     const bool hit = live && h.kind != 0;
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
     if (st2.twalk)
       st2.twalk += 3;
     n_rays += shade_hits<false, true, BS, VERIFY>(sc, bd, hit, h, b.x, b.y, b.z, a.w, pixel,
-                                                  depth, u0, u1, u2, st2);
+                                                  depth, u0, u1, u2, st2, lds_stack);
   }
   add_ray_count(ray_count, n_rays);
 }
@@ -497,8 +504,10 @@ __global__ __launch_bounds__(256) void k_check(SceneDev sc, CheckArgs a) {
   long rr = live ? r : 0;
   float ox = a.orig[3 * rr], oy = a.orig[3 * rr + 1], oz = a.orig[3 * rr + 2];
   float dx = a.dir[3 * rr], dy = a.dir[3 * rr + 1], dz = a.dir[3 * rr + 2];
-  Hit h = trace<false, false, ACCEL ? RT_ACCEL_BVH : RT_BEAM_NONE>(sc, live, ox, oy, oz,
-                                                                   dx, dy, dz);
+  __shared__ uint32_t walk_words[ACCEL ? LDS_STACK_ROWS * 256 : 1];
+  Hit h = trace<false, false, ACCEL ? RT_ACCEL_BVH : RT_BEAM_NONE>(
+      sc, live, ox, oy, oz, dx, dy, dz, 0.f, 0.f, 0.f, 0.f, ScreenStats{nullptr, nullptr, nullptr},
+      ACCEL ? walk_words + threadIdx.x : nullptr);
   if (live) {
     a.kind[r] = h.kind;
     a.index[r] = h.index;

@@ -183,41 +183,24 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
 }
 
 // ---- the lane's two small arrays in LDS -------------------------------------------
-// Word (row * 256 + thread): the 64 lanes of a wave hit 64 different banks whatever
-// row each of them is at.  Rows 0 .. TRACE_STACK_ROWS-1 are the lane's stack of
-// nodes still to visit, the next TRACE_PARK_ROWS its parked leaves; five blocks of
-// 31 KB share a CU's LDS (of five blocks of 32 KB the hardware runs only four).
-// A walk stacks at most three siblings per level of inner
-// nodes below which there are inner nodes (and one row more takes the stores that
-// do not count), so TRACE_STACK_ROWS rows serve trees of up to
-// TRACE_MAX_TREE_DEPTH levels of inner nodes (65 536 spheres when balanced);
-// the host sends deeper trees to the launch-per-level kernels.  A stack entry is
-// (16 bits of ordering key) << 16 | node index, hence at most 65 535 nodes.
+// Word (row * 256 + thread).  Rows 0 .. LDS_STACK_ROWS-1 are the lane's stack of
+// nodes still to visit (rt_device.h, stack_children), the next TRACE_PARK_ROWS its
+// parked leaves; five blocks of 31 KB share a CU's LDS (of five blocks of 32 KB
+// the hardware runs only four).  The host sends trees too deep for the LDS stack
+// to the launch-per-level kernels.
 //
-// The visit below is written without branches: every child is parked and pushed
-// by an unconditional store whose row only advances when the child qualifies (a
-// store that does not count is overwritten by the next one), and the touched
-// inner children are put in order by a five-step network of integer min / max on
-// the packed entries.  The straight-line form is less than half the instructions
-// of the branching one (per child a dozen exec-mask branches, each a handful of
-// scalar instructions and a wait for them), and a walk's pace is set by how many
-// instructions a wave issues per visit.  For the stores to stay in range a lane
-// never enters a visit with more than TRACE_PARK_FULL parked leaves: the wave works
-// the parked leaves off first (all lanes together, as at every refill).
-constexpr int TRACE_STACK_ROWS = 22;
+// The visit is written without branches: every child is parked by an
+// unconditional store whose row only advances when the child is a touched leaf, and
+// the touched inner children are ordered and pushed the same way.  A walk's pace is
+// set by how many instructions a wave issues per visit, and the branching form (per
+// child a dozen exec-mask branches, each a handful of scalar instructions and a
+// wait for them) was more than twice as many.  For the stores to stay in range a
+// lane never enters a visit with more than TRACE_PARK_FULL parked leaves: the wave
+// works the parked leaves off first (all lanes together, as at every refill).
 constexpr int TRACE_PARK_ROWS = 9;
 constexpr int TRACE_PARK_FULL = TRACE_PARK_ROWS - BVH_WIDTH;
-static_assert(3 * (TRACE_MAX_TREE_DEPTH - 1) + 1 <= TRACE_STACK_ROWS,
-              "three rows per level but the last, and the row the stores that do not count land in");
-static_assert((TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 1024 < 32768,
+static_assert((LDS_STACK_ROWS + TRACE_PARK_ROWS) * 1024 < 32768,
               "five blocks per CU: five times 32 KB, all of a CU's LDS, are not admitted");
-
-// Sorts two packed entries: a <= b afterwards.
-__device__ __forceinline__ void order2(uint32_t &a, uint32_t &b) {
-  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-  a = lo;
-  b = hi;
-}
 
 #ifdef RT_STAMPS
 // Diagnostic build only (make stamps): where a wave of k_trace spends its cycles.
@@ -270,9 +253,9 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   float len_s = RT_INF, bound = RT_INF;
   int idx_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
-  __shared__ uint32_t lds_words[(TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 256];
+  __shared__ uint32_t lds_words[(LDS_STACK_ROWS + TRACE_PARK_ROWS) * 256];
   uint32_t *const stack_l = lds_words + threadIdx.x; // stack_l[k * 256]: k-th stacked node
-  uint32_t *const park = stack_l + TRACE_STACK_ROWS * 256; // park[k * 256]: k-th parked leaf
+  uint32_t *const park = stack_l + LDS_STACK_ROWS * 256; // park[k * 256]: k-th parked leaf
   int sp = 0, node = 0;
   int n_park = 0;
   uint32_t n_rays = 0;
@@ -539,39 +522,19 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
       float near_key[BVH_WIDTH], entry_key[BVH_WIDTH];
       const BvhNode N = sc.bvh[node];
       bvh_visit2(N, qa.x, qa.y, qa.z, ix, iy, iz, ida, bound, touch, near_key, entry_key);
-      uint32_t e[BVH_WIDTH];
 #pragma unroll
       for (int c = 0; c < BVH_WIDTH; c++) {
-        const int32_t link = N.link[c];
         // a touched leaf is parked
+        const int32_t link = N.link[c];
         park[n_park * 256] = (uint32_t)link; // the leaf's slot is (~link) >> 3
         n_park += (touch[c] && link < 0) ? 1 : 0;
-        // a touched inner child becomes (key, node): shadow rays go first to the
-        // child entered first (the nearer an occluder is to the origin, the sooner
-        // the walk ends), the others to the child nearest to the world origin (it
-        // tightens `bound` soonest); 16 bits of either are plenty for an order
-        const uint32_t nk = (c & 1) ? (N.near_bits[c >> 1] & 0xffff0000u) : (N.near_bits[c >> 1] << 16);
-        const uint32_t ek = __float_as_uint(fmaxf(entry_key[c], 0.f)) & 0xffff0000u;
-        e[c] = (touch[c] && link >= 0) ? ((shadow ? ek : nk) | (uint32_t)link) : 0xffffffffu;
       }
-      order2(e[0], e[1]);
-      order2(e[2], e[3]);
-      order2(e[0], e[2]);
-      order2(e[1], e[3]);
-      order2(e[1], e[2]);
-      // the farthest goes on the stack first, the nearest is visited next
-#pragma unroll
-      for (int c = BVH_WIDTH - 1; c >= 1; c--) {
-        stack_l[sp * 256] = e[c];
-        sp += e[c] != 0xffffffffu ? 1 : 0;
-      }
-      uint32_t next = e[0];
-      if (next == 0xffffffffu && sp > 0)
-        next = stack_l[--sp * 256];
+      // the touched inner children: the nearest is visited next, the others stacked
+      const uint32_t next = stack_children(N, touch, entry_key, shadow, stack_l, sp);
 #ifdef RT_STAMPS
       dbg_near = __uint_as_float(next & 0xffff0000u);
 #endif
-      if (next != 0xffffffffu)
+      if (next != NO_ENTRY)
         node = (int)(next & 0xffffu);
       else
         state = DRAIN;
