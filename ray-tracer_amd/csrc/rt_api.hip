@@ -188,8 +188,9 @@ struct rt_scene {
   DevBuf<rt::TriRec> tri;
   DevBuf<uchar4> col_tri, col_sph;
   DevBuf<rt::BvhNode> bvh;
-  DevBuf<float4> leaf_geo;
+  DevBuf<float4> leaf_geo, leaf_mat;
   DevBuf<int32_t> leaf_idx;
+  DevBuf<uint64_t> ray_parts; // partial ray counters of the frame in flight (zero between frames)
   bool has_bvh = false;
   int bvh_depth = 0;     // levels of inner nodes
   size_t bvh_nodes = 0;
@@ -255,6 +256,7 @@ struct rt_scene {
     d.bvh = use_bvh ? bvh.p : nullptr;
     d.leaf_geo = use_bvh ? leaf_geo.p : nullptr;
     d.leaf_idx = use_bvh ? leaf_idx.p : nullptr;
+    d.leaf_mat = use_bvh ? leaf_mat.p : nullptr;
     d.bvh_lds = use_bvh && bvh_depth <= rt::LDS_WALK_MAX_DEPTH && bvh_nodes <= rt::LDS_WALK_MAX_NODES;
     const bool use_tbvh = has_tbvh && screen != 0;
     d.tbvh = use_tbvh ? tbvh.p : nullptr;
@@ -391,8 +393,11 @@ int scene_build(rt_scene *S, const scene_desc *s) {
           (rc = upload(S->leaf_idx, H.leaf_idx.data(), H.leaf_idx.size())))
         return rc;
       HIP_TRY(S->leaf_geo.alloc(H.leaf_idx.size()));
-      HIP_TRY(rt::launch_gather_leaves(S->sph_geo.p, S->leaf_idx.p, S->leaf_geo.p,
-                                       (int)H.leaf_idx.size(), nullptr));
+      HIP_TRY(S->leaf_mat.alloc(H.leaf_idx.size()));
+      HIP_TRY(rt::launch_gather_leaves(S->sph_geo.p, S->col_sph.p,
+                                       S->has_mat_sph ? S->mat_sph.p : nullptr, S->leaf_idx.p,
+                                       S->leaf_geo.p, S->leaf_mat.p, (int)H.leaf_idx.size(),
+                                       nullptr));
     }
   }
   // triangle hierarchy, once there are enough triangles for it to pay
@@ -416,6 +421,8 @@ int scene_build(rt_scene *S, const scene_desc *s) {
   S->eye_valid = false;
   S->screen = g_default_screen.load();
   S->trace_blocks = rt::trace_resident_blocks();
+  HIP_TRY(S->ray_parts.alloc((size_t)rt::RAY_PARTS * rt::RAY_PART_STRIDE));
+  HIP_TRY(hipMemset(S->ray_parts.p, 0, (size_t)rt::RAY_PARTS * rt::RAY_PART_STRIDE * sizeof(uint64_t)));
   HIP_TRY(hipEventCreateWithFlags(&S->ev_eye, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&S->ev_frame, hipEventDisableTiming));
   return RT_OK;
@@ -648,9 +655,26 @@ static int plan_frame(const rt_scene *S, const camera *cam, const rt_frame *fr, 
 // Enqueues the launches of one frame on the caller's stream.  A: the bounce
 // machinery (unused without bounces); side: a stream for the shadow walks, or
 // null to keep everything on the caller's stream.
+static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t side,
+                                 const camera *cam, const rt_frame *fr, const FramePlan &P,
+                                 uint64_t *dev_ray_count, uint64_t *dev_verify);
+
+// The kernels count rays in the scene's partial counters; the caller's word gets
+// their sum at the end of the frame.
 static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, const camera *cam,
                         const rt_frame *fr, const FramePlan &P, uint64_t *dev_ray_count,
                         uint64_t *dev_verify) {
+  const int rc = render_frame_launches(S, A, side, cam, fr, P,
+                                       dev_ray_count ? S->ray_parts.p : nullptr, dev_verify);
+  if (rc != RT_OK || !dev_ray_count)
+    return rc;
+  HIP_TRY(rt::launch_sum_rays(S->ray_parts.p, dev_ray_count, (hipStream_t)fr->stream));
+  return RT_OK;
+}
+
+static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t side,
+                                 const camera *cam, const rt_frame *fr, const FramePlan &P,
+                                 uint64_t *dev_ray_count, uint64_t *dev_verify) {
   hipStream_t st = (hipStream_t)fr->stream;
   rt::FrameDev f;
   f.fb = fr->dev_fb;

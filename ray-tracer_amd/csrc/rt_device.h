@@ -52,6 +52,7 @@ struct SceneDev {
   const float4 *leaf_geo;    // sph_geo gathered into leaf order
   const int32_t *leaf_idx;   // original sphere index of each leaf slot
   int bvh_lds;               // the tree fits a lane's LDS stack (LDS_STACK_ROWS)
+  const float4 *leaf_mat;    // per leaf slot: (kr, kt, ior, bits of the 8-bit colour)
   // hierarchy over the triangles (rt_tribvh.h); tbvh == nullptr: none, loop
   const TriNode *tbvh;
   const TriLeaf *tleaf;      // the triangles in leaf order, with their indices

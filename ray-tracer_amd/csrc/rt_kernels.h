@@ -28,10 +28,16 @@ struct EyeArgs {
   float ox, oy, oz;
 };
 
+// Rays are counted in RAY_PARTS partial counters, RAY_PART_STRIDE words apart (one
+// per 64-byte line), that k_sum_rays adds to the caller's word at the end of a
+// frame (rt_kernels.hip, add_ray_count).  Every `ray_count` below points to them.
+constexpr uint32_t RAY_PARTS = 256;
+constexpr uint32_t RAY_PART_STRIDE = 8;
+
 struct FrameDev {
   uint8_t *fb;   // 4 bytes per pixel, whole frame
   int32_t *ids;  // or nullptr
-  uint64_t *ray_count; // or nullptr
+  uint64_t *ray_count; // the partial counters, or nullptr
   int w, h;
   int max_depth;
   int band_rows, band_index, band_count;
@@ -149,8 +155,10 @@ int trace_resident_blocks();
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st);
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st);
-hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
-                                float4 *leaf_geo, int n, hipStream_t st);
+hipError_t launch_sum_rays(uint64_t *parts, uint64_t *total, hipStream_t st);
+hipError_t launch_gather_leaves(const float4 *sph_geo, const uchar4 *col_sph,
+                                const float4 *mat_sph, const int32_t *leaf_idx, float4 *leaf_geo,
+                                float4 *leaf_mat, int n, hipStream_t st);
 hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriLeaf *leaf,
                                     int n, hipStream_t st);
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);

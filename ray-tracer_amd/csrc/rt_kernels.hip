@@ -118,6 +118,13 @@ __device__ __forceinline__ Surface surface_at(const SceneDev &sc, const Hit &h) 
     s.ny = n.y;
     s.nz = n.z;
     col = sc.col_tri[h.index];
+  } else if (h.kind == 3) { // a sphere named by its leaf slot (k_trace)
+    const float4 g = sc.leaf_geo[h.index];
+    s.nx = h.Px - g.x;
+    s.ny = h.Py - g.y;
+    s.nz = h.Pz - g.z;
+    const uint32_t bits = __float_as_uint(sc.leaf_mat[h.index].w);
+    col = make_uchar4(bits & 0xffu, (bits >> 8) & 0xffu, (bits >> 16) & 0xffu, 0);
   } else { // renderer.cpp:71-74
     float4 g = sc.sph_geo[h.index];
     s.nx = h.Px - g.x;
@@ -181,6 +188,8 @@ __device__ __forceinline__ float phong_light(const Surface &s, const Hit &h,
 __device__ __forceinline__ float4 material_at(const SceneDev &sc, const Hit &h) {
   if (h.kind == 1)
     return sc.mat_tri ? sc.mat_tri[h.index] : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (h.kind == 3)
+    return sc.leaf_mat[h.index];
   return sc.mat_sph ? sc.mat_sph[h.index] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -339,15 +348,36 @@ shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
   return n_rays;
 }
 
-__device__ __forceinline__ void add_ray_count(uint64_t *counter, uint32_t n) {
-  if (!counter)
+// Rays traced by this wave, added to the frame's count: a wave sum, then one atomic
+// per wave on one of RAY_PARTS partial counters (64 bytes apart, chosen by block).
+// Atomics on one address retire one after the other, about 11 ns each: the 129 600
+// waves of a 4K primary pass adding to a single word took 1.4 ms, longer than the
+// pass itself.  k_sum_rays folds the partial counters into the caller's word.
+__device__ __forceinline__ void add_ray_count(uint64_t *parts, uint32_t n) {
+  if (!parts)
     return;
-  uint32_t v = n; // wave sum, then one atomic per wave
+  uint32_t v = n;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) {
+    const uint32_t part = (blockIdx.y * gridDim.x + blockIdx.x) % RAY_PARTS;
+    atomicAdd(reinterpret_cast<unsigned long long *>(parts) + part * RAY_PART_STRIDE,
+              (unsigned long long)v);
+  }
+}
+
+// One block of RAY_PARTS threads: total += the partial counters, which are cleared
+// for the next frame.
+__global__ void k_sum_rays(uint64_t *parts, uint64_t *total) {
+  unsigned long long *p = reinterpret_cast<unsigned long long *>(parts) + threadIdx.x * RAY_PART_STRIDE;
+  unsigned long long v = *p;
+  *p = 0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
     v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0 && v)
-    atomicAdd(reinterpret_cast<unsigned long long *>(counter), (unsigned long long)v);
+    atomicAdd(reinterpret_cast<unsigned long long *>(total), v);
 }
 
 // ---------------------------------------------------------------------------
@@ -650,6 +680,11 @@ extern "C" int rt_debug_trace_stamps(unsigned long long *out24) {
 }
 #endif
 
+hipError_t launch_sum_rays(uint64_t *parts, uint64_t *total, hipStream_t st) {
+  hipLaunchKernelGGL(k_sum_rays, dim3(1), dim3(RAY_PARTS), 0, st, parts, total);
+  return hipGetLastError();
+}
+
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st) {
   hipLaunchKernelGGL(k_compose, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0,
@@ -668,11 +703,21 @@ hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st) 
   return hipGetLastError();
 }
 
-__global__ void k_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
-                                float4 *leaf_geo, int n) {
+// Sphere records in leaf order: the geometry for the walks, and for the kernel
+// that names a hit sphere by its leaf slot (k_trace) material and colour in one
+// record, so that shading such a hit costs two scattered reads instead of three.
+__global__ void k_gather_leaves(const float4 *sph_geo, const uchar4 *col_sph,
+                                const float4 *mat_sph, const int32_t *leaf_idx, float4 *leaf_geo,
+                                float4 *leaf_mat, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    leaf_geo[i] = sph_geo[leaf_idx[i]];
+  if (i >= n)
+    return;
+  const int32_t k = leaf_idx[i];
+  leaf_geo[i] = sph_geo[k];
+  const uchar4 c = col_sph[k];
+  float4 m = mat_sph ? mat_sph[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+  m.w = __uint_as_float((uint32_t)c.x | ((uint32_t)c.y << 8) | ((uint32_t)c.z << 16));
+  leaf_mat[i] = m;
 }
 
 __global__ void k_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriLeaf *leaf,
@@ -699,12 +744,13 @@ hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, 
   return hipGetLastError();
 }
 
-hipError_t launch_gather_leaves(const float4 *sph_geo, const int32_t *leaf_idx,
-                                float4 *leaf_geo, int n, hipStream_t st) {
+hipError_t launch_gather_leaves(const float4 *sph_geo, const uchar4 *col_sph,
+                                const float4 *mat_sph, const int32_t *leaf_idx, float4 *leaf_geo,
+                                float4 *leaf_mat, int n, hipStream_t st) {
   if (n <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL(k_gather_leaves, dim3((n + 255) / 256), dim3(256), 0, st, sph_geo,
-                     leaf_idx, leaf_geo, n);
+  hipLaunchKernelGGL(k_gather_leaves, dim3((n + 255) / 256), dim3(256), 0, st, sph_geo, col_sph,
+                     mat_sph, leaf_idx, leaf_geo, leaf_mat, n);
   return hipGetLastError();
 }
 

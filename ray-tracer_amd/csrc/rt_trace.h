@@ -71,7 +71,7 @@ struct ShadeResult {
 };
 
 // Shades n (<= 64) hit records, one per lane: records hits[3 * (first + lane)].
-// A record is the ray's item followed by (P.xyz, bits of the sphere index or -1).
+// A record is the ray's item followed by (P.xyz, bits of the sphere's leaf slot or -1).
 __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *stack,
                                                    uint32_t sp, uint32_t cap,
                                                    uint32_t *overflow, const float4 *hits,
@@ -97,13 +97,13 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
     const uint32_t tag = __float_as_uint(qb.w);
     pixel = tag >> 6;
     depth = tag & 63u;
-    const int idx_s = __float_as_int(sh.w);
+    const int slot_s = __float_as_int(sh.w); // the sphere's leaf slot, or -1
     // |P| as the walk computed it: the same three products and sums (maths.cpp:23-25)
-    const float len_s = idx_s >= 0 ? length3(sh.x, sh.y, sh.z) : RT_INF;
+    const float len_s = slot_s >= 0 ? length3(sh.x, sh.y, sh.z) : RT_INF;
     float len_t = RT_INF, tPx = 0, tPy = 0, tPz = 0;
     int idx_t = -1;
     lane_triangles(sc, false, ox, oy, oz, dx, dy, dz, len_t, idx_t, tPx, tPy, tPz);
-    if (idx_t >= 0 || idx_s >= 0) { // renderer.cpp:179-192
+    if (idx_t >= 0 || slot_s >= 0) { // renderer.cpp:179-192
       if (len_t <= len_s) {
         h.kind = 1;
         h.index = idx_t;
@@ -111,8 +111,8 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
         h.Py = tPy;
         h.Pz = tPz;
       } else if (len_t > len_s) {
-        h.kind = 2;
-        h.index = idx_s;
+        h.kind = 3; // a sphere by its leaf slot (surface_at, material_at)
+        h.index = slot_s;
         h.Px = sh.x;
         h.Py = sh.y;
         h.Pz = sh.z;
@@ -251,7 +251,10 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa; // the lane's item
   float a = 0, a4 = 0, ix = 0, iy = 0, iz = 0, ida = 0;
   float len_s = RT_INF, bound = RT_INF;
-  int idx_s = -1;
+  // the nearest sphere so far is kept by its leaf slot: the walk never needs its
+  // index in the scene's arrays, except to settle a tie in |P| (renderer.cpp:170:
+  // the lower index wins), and a scattered read per accepted hit is saved
+  int slot_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
   __shared__ uint32_t lds_words[(LDS_STACK_ROWS + TRACE_PARK_ROWS) * 256];
   uint32_t *const stack_l = lds_words + threadIdx.x; // stack_l[k * 256]: k-th stacked node
@@ -291,7 +294,6 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           RT_TCOUNT(15, __builtin_popcountll(__ballot(k0 < n_park)));
           uint32_t slot[4];
           float4 g[4];
-          int id[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int k = k0 + j < TRACE_PARK_ROWS ? k0 + j : TRACE_PARK_ROWS - 1;
@@ -301,7 +303,6 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           for (int j = 0; j < 4; j++) {
             slot[j] = k0 + j < n_park ? (~slot[j]) >> 3 : 0u;
             g[j] = sc.leaf_geo[slot[j]];
-            id[j] = sc.leaf_idx[slot[j]];
           }
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
             const float c = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - g[j].w;                   // :129
             const float bb = b * b, ac = a4 * c;                                     // :132
             const bool may = (k0 + j < n_park) & !(bb < ac) & !((c > 0.f) & (b > 0.001f)) &
-                             !(shadow & (idx_s >= 0));
+                             !(shadow & (slot_s >= 0));
             if (__any(may)) {
               RT_TCOUNT(9, 1);
               RT_TCOUNT(14, __builtin_popcountll(__ballot(may)));
@@ -319,9 +320,11 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
                                        Pz)) {
                 const float len = length3(Px, Py, Pz);
                 // smallest |P|, lowest index on ties (renderer.cpp:168-177, order-free)
-                if (len < RT_INF && (len < len_s || (len == len_s && id[j] < idx_s))) {
+                if (len < RT_INF &&
+                    (len < len_s ||
+                     (len == len_s && sc.leaf_idx[slot[j]] < sc.leaf_idx[slot_s]))) {
                   len_s = len;
-                  idx_s = id[j];
+                  slot_s = (int)slot[j];
                   sPx = Px;
                   sPy = Py;
                   sPz = Pz;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
       // ---- hand in finished items ----
       {
         const bool done = state == DRAIN;
-        if (done && shadow && idx_s < 0) // unoccluded: renderer.cpp:119-127 as an integer sum
+        if (done && shadow && slot_s < 0) // unoccluded: renderer.cpp:119-127 as an integer sum
           add_light(t.extra, __float_as_uint(qa.w) & ~RT_ITEM_SHADOW, __float_as_uint(qb.w));
         const bool rec = done && !shadow;
         const unsigned long long m = __ballot(rec);
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
                                                        m & ((1ull << lane) - 1ull)));
           r[0] = qa;
           r[1] = qb;
-          r[2] = make_float4(sPx, sPy, sPz, __int_as_float(idx_s));
+          r[2] = make_float4(sPx, sPy, sPz, __int_as_float(slot_s));
         }
         n_hits += (uint32_t)__builtin_popcountll(m);
         if (done)
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
         // walks in progress step aside: their state goes to the wave's save area
         save[0 * 64] = qa;
         save[1 * 64] = qb;
-        save[2 * 64] = make_float4(len_s, bound, __int_as_float(idx_s), sPx);
+        save[2 * 64] = make_float4(len_s, bound, __int_as_float(slot_s), sPx);
         save[3 * 64] = make_float4(sPy, sPz, __int_as_float(sp), __int_as_float(node));
         save[4 * 64] = make_float4(__int_as_float(n_park | (state << 8) | ((int)shadow << 16)),
                                    __uint_as_float(n_rays), 0.f, 0.f);
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           qb = save[1 * 64];
           len_s = s2.x;
           bound = s2.y;
-          idx_s = __float_as_int(s2.z);
+          slot_s = __float_as_int(s2.z);
           sPx = s2.w;
           sPy = s3.x;
           sPz = s3.y;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           shadow = (__float_as_uint(qa.w) & RT_ITEM_SHADOW) != 0;
           n_rays++;
           len_s = RT_INF;
-          idx_s = -1;
+          slot_s = -1;
           bound = RT_INF;
           sp = 0;
           node = 0;
@@ -478,16 +481,18 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           if (!(a > 0.f) || sc.s_size == 0) {
             state = DRAIN; // no sphere can be hit (rt_device.h, beam screen notes)
           } else if (!sane) {
-            // out-of-range direction length: this lane tests every sphere
-            for (int i = 0; i < sc.s_size; i++) {
-              const float4 g = sc.sph_geo[i];
+            // out-of-range direction length: this lane tests every sphere (every
+            // sphere has a leaf slot)
+            for (int k = 0; k < sc.s_size; k++) {
+              const float4 g = sc.leaf_geo[k];
               float Px, Py, Pz;
               if (sphere_exact(g.x, g.y, g.z, g.w, a, a4, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, Px,
                                Py, Pz)) {
                 const float len = length3(Px, Py, Pz);
-                if (len_s > len) {
+                if (len < RT_INF &&
+                    (len < len_s || (len == len_s && sc.leaf_idx[k] < sc.leaf_idx[slot_s]))) {
                   len_s = len;
-                  idx_s = i;
+                  slot_s = k;
                   sPx = Px;
                   sPy = Py;
                   sPz = Pz;

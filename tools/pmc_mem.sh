@@ -6,7 +6,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_mem
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --side-stream 0 $*"
+ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plain-loop --frames-in-flight 1 --side-stream 0 $*"
 pass() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" -d $OUT/$name -o pmc -- python3 $ARGS > $OUT/$name.log 2>&1 || { echo "$name failed"; tail -3 $OUT/$name.log; exit 1; }

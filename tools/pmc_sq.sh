@@ -5,7 +5,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_sq
 rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --side-stream 0 $*"
+ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plain-loop --frames-in-flight 1 --side-stream 0 $*"
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/sq -o pmc -- python3 $ARGS > $OUT/sq.log 2>&1 || { echo "sq failed"; tail -3 $OUT/sq.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INST_CYCLES_VMEM -d $OUT/sq2 -o pmc -- python3 $ARGS > $OUT/sq2.log 2>&1 || { echo "sq2 failed"; tail -3 $OUT/sq2.log; exit 1; }
 python3 - $OUT <<'PY'
