@@ -35,7 +35,10 @@ typedef struct rt_host_scene {
  *   RT_BLANK_PHANTOM  a blank line appends an all-zero primitive of the type of
  *                     the last parsed line, which reproduces the reference's
  *                     usual counts (8 triangles for the shipped scene.txt);
- *                     all-zero triangles are degenerate and can never be hit */
+ *                     all-zero triangles are degenerate and can never be hit.
+ *                     A file that ends in a newline gets one more such primitive:
+ *                     the reference's `while (!file.eof())` (main.cpp:228) reads
+ *                     an empty line after it                                  */
 enum { RT_BLANK_SKIP = 0, RT_BLANK_PHANTOM = 1 };
 
 /* Returns 0, or -1 (cannot open), -2 (malformed line; *bad_line = 1-based line

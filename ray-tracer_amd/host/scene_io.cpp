@@ -35,21 +35,25 @@ int rt_host_load_scene(const char *path, int blank_mode, rt_host_scene *out,
   std::string line;
   int lineno = 0;
   char last_type = 0;
+  bool last_line_ended = false; // the last line read ended in '\n'
+  auto phantom = [&]() {
+    if (last_type == 's')
+      vs.insert(vs.end(), 7, 0.0f);
+    else if (last_type == 't')
+      vt.insert(vt.end(), 12, 0.0f);
+    else if (last_type == 'l')
+      vl.insert(vl.end(), 3, 0.0f);
+  };
   while (std::getline(file, line)) {
     lineno++;
+    last_line_ended = !file.eof();
     if (!line.empty() && line[0] == '/') // main.cpp:232
       continue;
     std::istringstream stream(line);
     char type = 0;
     if (!(stream >> type)) { // blank line
-      if (blank_mode == RT_BLANK_PHANTOM) {
-        if (last_type == 's')
-          vs.insert(vs.end(), 7, 0.0f);
-        else if (last_type == 't')
-          vt.insert(vt.end(), 12, 0.0f);
-        else if (last_type == 'l')
-          vl.insert(vl.end(), 3, 0.0f);
-      }
+      if (blank_mode == RT_BLANK_PHANTOM)
+        phantom();
       continue;
     }
     int want = type == 's' ? 7 : type == 't' ? 12 : type == 'l' ? 3 : 0; // main.cpp:242-263
@@ -66,6 +70,11 @@ int rt_host_load_scene(const char *path, int blank_mode, rt_host_scene *out,
       dst.push_back(val);
     }
   }
+  // The reference loops `while (!file.eof())` (main.cpp:228): after a file whose last
+  // byte is '\n' it reads one more, empty, line and appends one more primitive of
+  // the last type.
+  if (blank_mode == RT_BLANK_PHANTOM && lineno > 0 && last_line_ended)
+    phantom();
   const int nt = (int)(vt.size() / 12), ns = (int)(vs.size() / 7), nl = (int)(vl.size() / 3);
   std::vector<float> tris(9 * (size_t)nt), sph(3 * (size_t)ns), rad(ns), lights(3 * (size_t)nl);
   std::vector<uint8_t> ct(3 * (size_t)nt), cs(3 * (size_t)ns);

@@ -122,6 +122,31 @@ def test_loader_matches_reference_on_a_file_without_blank_lines(host, ref, tmp_p
         assert np.array_equal(getattr(mine, f), getattr(theirs, f)), f
 
 
+def test_loader_phantom_after_a_trailing_newline(host, ref, tmp_path):
+    """The reference loops `while (!file.eof())` (main.cpp:228): a file that ends in
+    a newline makes it read one more, empty, line and append one more primitive of
+    the last line's type (here a light).  Phantom mode does the same; the counts are
+    checked against the reference's own reader."""
+    p = tmp_path / "nl.txt"
+    p.write_text("s 1.0 0 0 -5  1 2 3\nl 0.0 5.0 1.0\n")
+    rc, mine = load(host, p, mode=1)
+    assert rc == 0
+    assert (mine.s_size, mine.t_size, mine.l_size) == (1, 0, 2)
+    assert np.array_equal(mine.lights[0], np.array([0, 5, 1], np.float32))
+    assert (mine.lights[1] == 0).all()
+    theirs = ref.read_scene(str(p))
+    assert (theirs.s_size, theirs.t_size, theirs.l_size) == (mine.s_size, mine.t_size, mine.l_size)
+    assert np.array_equal(theirs.lights[0], mine.lights[0])
+    # without the newline neither appends anything
+    p.write_text("s 1.0 0 0 -5  1 2 3\nl 0.0 5.0 1.0")
+    rc, mine = load(host, p, mode=1)
+    assert rc == 0 and (mine.s_size, mine.t_size, mine.l_size) == (1, 0, 1)
+    # the defined behaviour ignores the empty last line
+    p.write_text("s 1.0 0 0 -5  1 2 3\nl 0.0 5.0 1.0\n")
+    rc, mine = load(host, p, mode=0)
+    assert rc == 0 and (mine.s_size, mine.t_size, mine.l_size) == (1, 0, 1)
+
+
 def test_grid_generator(host, golden):
     for row, col in [(10, 10), (3, 7), (32, 32)]:
         hs = HostScene()
