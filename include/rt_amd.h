@@ -229,6 +229,16 @@ int rt_scene_set_one_launch(rt_scene *scene, int on);
 int rt_scene_time_kernels(rt_scene *scene, int on);
 int rt_scene_kernel_times(rt_scene *scene, float ms[3]);
 
+/* Which machinery a scene's frames use (no counterpart in the reference; for
+ * tests and for hosts that want to know what they pay for).  info[0] nodes of
+ * the sphere hierarchy (0: none), info[1] its levels of inner nodes, info[2] 1 if
+ * the walks keep their stacks in LDS (trees of at most 8 levels and 65 535
+ * nodes; deeper ones use per-lane stacks in scratch memory), info[3] 1 if a frame
+ * with bounces runs its bounce levels as one launch (rt_scene_set_one_launch and
+ * the conditions listed there), info[4] nodes of the triangle hierarchy (0:
+ * none), info[5..7] 0.                                                         */
+int rt_scene_describe(const rt_scene *scene, int64_t info[8]);
+
 /* As rt_render_device, with a slow self-checking build of the kernel that
  * re-tests every sphere the screen dropped.  dev_stats (device, 16 x uint64,
  * zeroed by the caller) receives

@@ -198,6 +198,7 @@ struct rt_scene {
   DevBuf<rt::TriLeaf> tleaf;
   DevBuf<int32_t> tloose;
   bool has_tbvh = false;
+  size_t tbvh_nodes = 0;
   bool has_mat_tri = false, has_mat_sph = false;
   int screen = 1;      // rt_scene_set_screen
   int side_stream = 1; // rt_scene_set_side_stream
@@ -405,6 +406,7 @@ int scene_build(rt_scene *S, const scene_desc *s) {
     rt::TriBvhHost H;
     rt::tri_bvh_build(s->tris, s->t_size, H);
     S->has_tbvh = H.valid && !H.nodes.empty();
+    S->tbvh_nodes = H.nodes.size();
     if (S->has_tbvh) {
       DevBuf<int32_t> order; // leaf slot -> triangle; only the gather needs it
       if ((rc = upload(S->tbvh, H.nodes.data(), H.nodes.size())) ||
@@ -1032,6 +1034,19 @@ int rt_scene_kernel_times(rt_scene *S, float ms[3]) {
   HIP_TRY(hipEventSynchronize(S->ev_t[S->timed_stages]));
   for (int k = 0; k < S->timed_stages; k++)
     HIP_TRY(hipEventElapsedTime(&ms[k], S->ev_t[k], S->ev_t[k + 1]));
+  return RT_OK;
+}
+
+int rt_scene_describe(const rt_scene *S, int64_t info[8]) {
+  if (!S || !info)
+    return fail(RT_ERR_BAD_ARG, "scene or info is NULL");
+  for (int k = 0; k < 8; k++)
+    info[k] = 0;
+  info[0] = S->has_bvh ? (int64_t)S->bvh_nodes : 0;
+  info[1] = S->has_bvh ? S->bvh_depth : 0;
+  info[2] = bvh_fits_lds(S) ? 1 : 0;
+  info[3] = uses_trace(S) ? 1 : 0;
+  info[4] = S->has_tbvh ? (int64_t)S->tbvh_nodes : 0;
   return RT_OK;
 }
 

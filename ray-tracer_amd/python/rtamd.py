@@ -169,6 +169,7 @@ def lib() -> C.CDLL:
     L.rt_scene_set_screen.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_set_side_stream.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_set_one_launch.argtypes = [C.c_void_p, C.c_int]
+    L.rt_scene_describe.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.rt_scene_time_kernels.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.rt_scene_set_rays_per_pixel.argtypes = [C.c_void_p, C.c_int]
@@ -306,6 +307,13 @@ class DeviceScene:
     def set_screen(self, mode):
         """rt_scene_set_screen: the work-avoidance mode of this scene's later frames."""
         _check(lib().rt_scene_set_screen(self.handle, _mode(mode)))
+
+    def describe(self):
+        """rt_scene_describe as a dict."""
+        info = (C.c_int64 * 8)()
+        _check(lib().rt_scene_describe(self.handle, info))
+        return {"sphere_nodes": info[0], "sphere_levels": info[1], "lds_stacks": bool(info[2]),
+                "one_launch": bool(info[3]), "triangle_nodes": info[4]}
 
     def time_kernels(self, on: bool = True):
         """rt_scene_time_kernels: record events around the stages of later frames."""

@@ -268,3 +268,36 @@ def test_mesh_80k_720p_depth4_every_row_equals_the_plain_loop():
         f0, i0, n0 = _device_frame(ds, 1280, 720, 4, "off")
         f1, i1, n1 = _device_frame(ds, 1280, 720, 4, "auto")
         assert n0 == n1 and torch.equal(i0, i1) and torch.equal(f0, f1)
+
+
+def test_which_machinery_a_scene_uses():
+    """rt_scene_describe: the bench scene walks with LDS stacks and runs its bounce
+    levels as one launch; a tree of more than 65 535 nodes does neither."""
+    with rtamd.DeviceScene(rtamd.material_grid_scene(100, 100)) as ds:
+        d = ds.describe()
+        assert d["sphere_nodes"] > 3000 and d["sphere_levels"] <= 8
+        assert d["lds_stacks"] and d["one_launch"] and d["triangle_nodes"] == 0
+        ds.set_one_launch(False)
+        assert not ds.describe()["one_launch"]
+    with rtamd.DeviceScene(rtamd.material_grid_scene(500, 500)) as ds:
+        d = ds.describe()
+        assert d["sphere_nodes"] > 65535 and not d["lds_stacks"] and not d["one_launch"]
+
+
+def test_tree_too_large_for_the_lds_stacks(oracle):
+    """250 000 spheres: more nodes than a 16-bit stack entry can name, so the walks
+    use their private stacks and the bounce levels run as a launch per stage.  Every
+    row equals the plain loop's frame, sampled rows equal the oracle's."""
+    sc = rtamd.material_grid_scene(500, 500)
+    w, h, depth = 640, 360, 4
+    try:
+        fb, ids, n = rtamd.render(sc, w, h, max_depth=depth)
+        rtamd.set_screen("off")
+        fb0, ids0, n0 = rtamd.render(sc, w, h, max_depth=depth)
+    finally:
+        rtamd.set_screen("auto")
+    assert n == n0 and np.array_equal(ids, ids0) and np.array_equal(fb, fb0)
+    rows = (7, h, 60)
+    fo, io, _ = oracle.render(sc, w, h, max_depth=depth, rows=rows)
+    sel = slice(*rows)
+    assert np.array_equal(ids[sel], io[sel]) and np.array_equal(fb[sel], fo[sel])
