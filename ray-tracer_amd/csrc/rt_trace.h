@@ -37,10 +37,7 @@ namespace rt {
 // The sign bit of the fourth word tells them apart (a weight is positive, a pixel
 // index is below 2^26).
 #define RT_ITEM_SHADOW 0x80000000u
-// a block that has used up a segment of the frame's queue goes on to the segment
-// this many further (odd, so that every segment is reached)
-constexpr uint32_t QUEUE_HOP = 37;
-static_assert(QUEUE_SEGMENTS % 2 == 0 && QUEUE_HOP % 2 == 1, "the hops must reach every segment");
+static_assert(QUEUE_SEGMENTS % 64 == 0, "k_trace looks for work in 64 segments at a time");
 
 // The wave's stack of items: push for the lanes with `want`, consecutive slots in
 // lane order.  Returns the new height.  An item that does not fit is dropped
@@ -232,7 +229,6 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   // or cheap work is done long before the others: the mean wave lived 70 % of the
   // longest one.
   uint32_t seg = my_segment();
-  uint32_t segs_left = QUEUE_SEGMENTS - 1;
   uint32_t n_in = t.in.count[seg * CTL_WORDS];
   if (n_in > t.in.seg_capacity)
     n_in = t.in.seg_capacity;
@@ -445,18 +441,31 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
             }
           }
           if (base + (uint32_t)n_e >= n_in) {
-            // this segment is used up: on to the next one (lanes it could not
-            // serve are served at the next refill), or nothing is left
-            if (segs_left == 0) {
-              drained = true;
-            } else {
-              segs_left--;
-              seg = (seg + QUEUE_HOP) % QUEUE_SEGMENTS;
-              n_in = t.in.count[seg * CTL_WORDS];
-              if (n_in > t.in.seg_capacity)
-                n_in = t.in.seg_capacity;
+            // This segment is used up: on to the next one that still has rays to
+            // hand out (lanes it could not serve are served at the next refill), or
+            // nothing is left.  The lanes look at 64 segments at a time; a cursor
+            // read here may be behind, which only costs a useless attempt later.
+            bool found = false;
+            for (uint32_t round = 0; round < QUEUE_SEGMENTS / 64 && !found; round++) {
+              const uint32_t s = (seg + 1 + round * 64 + (uint32_t)lane) % QUEUE_SEGMENTS;
+              uint32_t n = t.in.count[s * CTL_WORDS];
+              if (n > t.in.seg_capacity)
+                n = t.in.seg_capacity;
+              const uint32_t c = __hip_atomic_load(t.cursor + s * CTL_WORDS, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned long long m = __ballot(c < n);
+              if (m != 0) {
+                const int first = __builtin_ctzll(m);
+                seg = (uint32_t)__builtin_amdgcn_readlane((int)s, first);
+                n_in = (uint32_t)__builtin_amdgcn_readlane((int)n, first);
+                found = true;
+              }
+            }
+            if (found) {
               seg_base = (size_t)seg * t.in.seg_capacity;
               cursor = t.cursor + seg * CTL_WORDS;
+            } else {
+              drained = true;
             }
           }
         }
