@@ -388,8 +388,11 @@ __global__ void k_sum_rays(uint64_t *parts, uint64_t *total) {
 // block's pixel writes cover 128 contiguous bytes per row.  blockIdx.y counts
 // the tile rows this call owns; bands of band_rows rows are dealt round-robin
 // over band_count callers (row sharding, renderer.cpp:27-28).
+// Five waves per SIMD (96 registers, a hundred bytes more scratch than at 123
+// registers and four waves): the pass waits on dependent node reads, and the fifth
+// wave is worth more than the spills cost (depth-1 4K frame 1.01 -> 0.96 ms).
 template <int ACCEL, bool VERIFY, bool MATERIALS>
-__global__ __launch_bounds__(256) void k_render(SceneDev sc, CameraDev cam,
+__global__ __launch_bounds__(256, 5) void k_render(SceneDev sc, CameraDev cam,
                                                 FrameDev f, BounceDev bd,
                                                 ScreenStats st) {
   const int lane = threadIdx.x & 63;
