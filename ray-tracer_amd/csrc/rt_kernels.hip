@@ -267,7 +267,7 @@ __device__ __forceinline__ void queue_push(const RayQueue &q, bool want, float o
 // PRIMARY: the hit of the pixel's own ray; light is accumulated into fb0..2 with
 // the reference's float form.  Otherwise light is added to the pixel's integer
 // side sums.  Returns the number of shadow rays this lane traced.
-template <bool PRIMARY, bool MATERIALS, int BEAM, bool VERIFY>
+template <bool PRIMARY, bool MATERIALS, int BEAM, bool VERIFY, bool TRI_TREE = true>
 __device__ __forceinline__ uint32_t
 shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
            float dx, float dy, float dz, float w, uint32_t pixel, uint32_t depth,
@@ -300,7 +300,7 @@ shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
       }
       // renderer.cpp:119: shadow ray from exactly P, no distance limit.  All
       // shadow rays of the wave aim at the light: that is the beam's apex.
-      Hit sh = trace<false, true, BEAM, VERIFY>(sc, lit, h.Px, h.Py, h.Pz, lx, ly,
+      Hit sh = trace<false, true, BEAM, VERIFY, TRI_TREE>(sc, lit, h.Px, h.Py, h.Pz, lx, ly,
                                                 lz, light.x, light.y, light.z,
                                                 dist, st, lds_stack);
       if (lit) {
@@ -391,7 +391,7 @@ __global__ void k_sum_rays(uint64_t *parts, uint64_t *total) {
 // Five waves per SIMD (96 registers, a hundred bytes more scratch than at 123
 // registers and four waves): the pass waits on dependent node reads, and the fifth
 // wave is worth more than the spills cost (depth-1 4K frame 1.01 -> 0.96 ms).
-template <int ACCEL, bool VERIFY, bool MATERIALS>
+template <int ACCEL, bool VERIFY, bool MATERIALS, bool TRI_TREE>
 __global__ __launch_bounds__(256, 5) void k_render(SceneDev sc, CameraDev cam,
                                                 FrameDev f, BounceDev bd,
                                                 ScreenStats st) {
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 5) void k_render(SceneDev sc, CameraDev cam,
   // the lanes' stacks of the sphere walk (rt_device.h, walk_spheres_lds)
   __shared__ uint32_t walk_words[ACCEL == RT_ACCEL_BVH ? LDS_STACK_ROWS * 256 : 1];
   uint32_t *const lds_stack = ACCEL == RT_ACCEL_BVH ? walk_words + threadIdx.x : nullptr;
-  Hit h = trace<true, false, BM, VERIFY>(sc, inside, cam.ox, cam.oy, cam.oz, dx,
+  Hit h = trace<true, false, BM, VERIFY, TRI_TREE>(sc, inside, cam.ox, cam.oy, cam.oz, dx,
                                          dy, dz, cam.ox, cam.oy, cam.oz, 0.f, st, lds_stack);
 
   uint32_t fb0 = 0, fb1 = 0, fb2 = 0; // renderer.cpp:50-52
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 5) void k_render(SceneDev sc, CameraDev cam,
       fb2 = col.z;
     }
   } else {
-    n_rays += shade_hits<true, MATERIALS, BM, VERIFY>(sc, bd, hit, h, dx, dy, dz, 1.0f,
+    n_rays += shade_hits<true, MATERIALS, BM, VERIFY, TRI_TREE>(sc, bd, hit, h, dx, dy, dz, 1.0f,
                                                       (uint32_t)p, 1u, fb0, fb1, fb2, st,
                                                       lds_stack);
   }
@@ -579,7 +579,12 @@ hipError_t launch_render(const SceneDev &sc, const CameraDev &cam,
   ScreenStats ss{nullptr, nullptr, nullptr};
   const bool mats = bd.max_depth > 1;
 #define RT_LAUNCH(A, V, M)                                                               \
-  hipLaunchKernelGGL((k_render<A, V, M>), grid, dim3(256), 0, st, sc, cam, f, bd, ss)
+  do {                                                                                   \
+    if (sc.tbvh != nullptr)                                                              \
+      hipLaunchKernelGGL((k_render<A, V, M, true>), grid, dim3(256), 0, st, sc, cam, f, bd, ss);  \
+    else                                                                                 \
+      hipLaunchKernelGGL((k_render<A, V, M, false>), grid, dim3(256), 0, st, sc, cam, f, bd, ss); \
+  } while (0)
   if (verify_stats) {
     ss.dropped_but_candidate = verify_stats;
     ss.kept = verify_stats + 1;

@@ -138,7 +138,7 @@ __device__ unsigned long long g_stamps[16];
 #endif
 
 template <bool ANY_HIT, bool TRI>
-__global__ __launch_bounds__(256, TRI ? 5 : 6) void k_walk(SceneDev sc, WalkArgs w) {
+__global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
   const int lane = threadIdx.x & 63;
 #ifdef RT_STAMPS
   unsigned long long st_serv = 0, st_load = 0, st_visit = 0, st_fetch = 0, n_serv = 0, n_visit = 0;
@@ -162,7 +162,9 @@ __global__ __launch_bounds__(256, TRI ? 5 : 6) void k_walk(SceneDev sc, WalkArgs
   float len_s = RT_INF, bound = RT_INF;
   int idx_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
-  PrivateStack stack;
+  __shared__ int stack_words[LDS_STACK_ROWS * 256];
+  LdsStack stack;
+  stack.lds = stack_words + threadIdx.x;
   int sp = 0, node = 0;
   __shared__ int park_words[PARK_SLOTS * 256];
   int *const park = park_words + threadIdx.x; // park[k * 256]: this lane's k-th parked leaf
