@@ -521,18 +521,11 @@ __device__ __forceinline__ void bvh_visit(const BvhNode &N, float ox, float oy, 
     bvh_visit2(N, ox, oy, oz, ix, iy, iz, ida, bound, touch, key, other);
 }
 
-// Sorts two packed entries: a <= b afterwards.
-__device__ __forceinline__ void order2(uint32_t &a, uint32_t &b) {
-  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-  a = lo;
-  b = hi;
-}
-
 constexpr uint32_t NO_ENTRY = 0xffffffffu;
 
 // What a visit does with the touched inner children, written without branches: each
-// becomes an entry (key, node), a five-step network of integer min / max puts the
-// entries in order, the farther ones go on the lane's LDS stack by unconditional
+// becomes an entry (key, node), integer min / max bring the one with the smallest
+// key to the front, the others go on the lane's LDS stack by unconditional
 // stores whose row only advances for a real entry (a store that does not count is
 // overwritten by the next one), and the nearest one, or failing that the top of the
 // stack, is returned (NO_ENTRY: the walk is over).  by_entry: order by the
@@ -553,11 +546,17 @@ __device__ __forceinline__ uint32_t stack_children(const BvhNode &N, const bool 
     const uint32_t ek = __float_as_uint(fmaxf(entry_key[c], 0.f)) & 0xffff0000u;
     e[c] = (touch[c] && link >= 0) ? ((by_entry ? ek : nk) | (uint32_t)link) : NO_ENTRY;
   }
-  order2(e[0], e[1]);
-  order2(e[2], e[3]);
-  order2(e[0], e[2]);
-  order2(e[1], e[3]);
-  order2(e[1], e[2]);
+  // the smallest entry to the front (three steps of integer min / max); the other
+  // three go on the stack as they come (ordering them all, two steps more, was
+  // measured half a percent slower)
+  {
+    const uint32_t m01 = e[0] < e[1] ? e[0] : e[1], x01 = e[0] < e[1] ? e[1] : e[0];
+    const uint32_t m23 = e[2] < e[3] ? e[2] : e[3], x23 = e[2] < e[3] ? e[3] : e[2];
+    e[0] = m01 < m23 ? m01 : m23;
+    e[1] = m01 < m23 ? m23 : m01;
+    e[2] = x01;
+    e[3] = x23;
+  }
 #pragma unroll
   for (int c = BVH_WIDTH - 1; c >= 1; c--) {
     stack_l[sp * 256] = e[c];
