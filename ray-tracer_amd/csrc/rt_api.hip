@@ -77,6 +77,7 @@ constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
 // A bounce ray carries its pixel in the upper 26 bits of a 32-bit tag
 // (pixel << 6 | depth, rt_kernels.hip queue_push).
 constexpr size_t kMaxBouncePixels = (size_t)1 << 26;
+constexpr size_t kSmallSharePixels = 1500000; // see bounce_needs
 
 // What the bounce levels of one frame need besides the scene: ray queues, hit
 // lists, shadow items, control words and the per-pixel integer sums.  All of it
@@ -493,7 +494,13 @@ BounceNeeds bounce_needs(const rt_scene *S, int max_depth, size_t frame_pixels,
     const int lights = S->l_size > 0 ? S->l_size : 1;
     n.stack_cap = (uint32_t)(64 * (2 + lights) * (max_depth + 2) *
                              std::max(1, S->rays_per_pixel / 4));
+    // A small share of a frame (one rank's bands of an N-way split) runs on half the
+    // resident grid: its waves then get enough rays to keep their lanes busy, and
+    // the other half of the chip is free for the frames beside it (1/8 share with
+    // four frames in flight 1.12 -> 1.02 ms; a whole frame on half the grid loses).
     int blocks = S->trace_blocks;
+    if (owned_pixels < kSmallSharePixels && blocks >= 128)
+      blocks /= 2;
     n.trace_waves = (size_t)blocks * 4;
     if (max_bytes) {
       BounceArena probe;
@@ -616,6 +623,7 @@ struct FramePlan {
   int owned_tile_rows = 0;
   bool bounces = false;
   bool unlit = false;
+  int trace_blocks = 0; // grid of the one-launch bounce kernel for this frame (bounce_needs)
 };
 
 static int plan_frame(const rt_scene *S, const camera *cam, const rt_frame *fr, FramePlan &P) {
@@ -743,7 +751,7 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
     ta.overflow = A->overflow_flag();
     ta.max_depth = fr->max_depth;
     ta.fetch_at = rt::WALK_FETCH_AT;
-    HIP_TRY(rt::launch_trace(sd, ta, (int)(A->have.trace_waves / 4), st));
+    HIP_TRY(rt::launch_trace(sd, ta, P.trace_blocks, st)); // <= A->have.trace_waves / 4
     if (S->timing)
       HIP_TRY(hipEventRecord(S->ev_t[2], st));
     HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, (size_t)fr->w * fr->h, st));
@@ -870,6 +878,7 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
     const BounceNeeds need = bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
                                           (size_t)P.owned_tile_rows * 8 * fr->w);
     S->one_launch = one_launch;
+    P.trace_blocks = (int)(need.trace_waves / 4);
     if ((rc = ensure_arena(S, need)))
       return rc;
   }
@@ -952,6 +961,7 @@ int rt_render_device_noalloc(rt_scene *S, const camera *cam, const rt_frame *fr,
     const BounceNeeds need =
         bounce_needs(S, fr->max_depth, (size_t)fr->w * fr->h,
                      (size_t)P.owned_tile_rows * 8 * fr->w, RT_NOALLOC_SCRATCH_BYTES);
+    P.trace_blocks = (int)(need.trace_waves / 4);
     const size_t bytes = A.carve(nullptr, need);
     if (bytes > (size_t)RT_NOALLOC_SCRATCH_BYTES)
       return fail(RT_ERR_CAPACITY,
