@@ -18,9 +18,10 @@ fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
 L = rtamd.lib()
 out = (C.c_ulonglong * 24)()
 with rtamd.DeviceScene(sc) as ds:
-    ds.set_one_launch(True)
+    ds.set_one_launch(int(os.environ.get("ONE_LAUNCH", "1")))
     for k in range(4):
-        ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth)
+        ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth, band_rows=8, band_index=0,
+                         band_count=int(os.environ.get("SHARE", "1")))
         torch.cuda.synchronize()
         L.rt_debug_trace_stamps(out)
 v = [float(x) for x in out]
