@@ -205,6 +205,7 @@ struct rt_scene {
   int side_stream = 1; // rt_scene_set_side_stream
   int one_launch = 1;  // rt_scene_set_one_launch
   int trace_blocks = 1024; // resident blocks of k_trace on this device
+  int walk_blocks = 1024;  // of k_walk
   // Eye-relative records (k_prep_eye) are rebuilt only when the eye moves.  The
   // rebuild runs on the stream of the frame that asks for it; ev_eye lets frames
   // on other streams wait for it, ev_frame marks the end of the last frame's
@@ -424,6 +425,7 @@ int scene_build(rt_scene *S, const scene_desc *s) {
   S->eye_valid = false;
   S->screen = g_default_screen.load();
   S->trace_blocks = rt::trace_resident_blocks();
+  S->walk_blocks = rt::walk_resident_blocks();
   HIP_TRY(S->ray_parts.alloc((size_t)rt::RAY_PARTS * rt::RAY_PART_STRIDE));
   HIP_TRY(hipMemset(S->ray_parts.p, 0, (size_t)rt::RAY_PARTS * rt::RAY_PART_STRIDE * sizeof(uint64_t)));
   HIP_TRY(hipEventCreateWithFlags(&S->ev_eye, hipEventDisableTiming));
@@ -787,13 +789,13 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
     wa.cursor = A->ctl(level, 1);
     wa.hits = hl;
     wa.ray_count = dev_ray_count;
-    HIP_TRY(rt::launch_walk(sd, wa, false, false, kBounceBlocks, st));
+    HIP_TRY(rt::launch_walk(sd, wa, false, false, S->walk_blocks, st));
     if (tri_walks) {
       wa.cursor = A->ctl(level, 2);
       wa.hits = tl;
       wa.prior = hl;
       wa.ray_count = nullptr;
-      HIP_TRY(rt::launch_walk(sd, wa, false, true, kBounceBlocks, st));
+      HIP_TRY(rt::launch_walk(sd, wa, false, true, S->walk_blocks, st));
     }
     rt::ShadeArgs sa;
     memset(&sa, 0, sizeof sa);
@@ -836,12 +838,12 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
         ws.cursor = A->ctl(level, 4 + 3 * g);
         ws.ray_count = dev_ray_count;
         ws.last_stage = tri_walks ? 0 : 1;
-        HIP_TRY(rt::launch_walk(sd, ws, true, false, kBounceBlocks, ws_stream));
+        HIP_TRY(rt::launch_walk(sd, ws, true, false, S->walk_blocks, ws_stream));
         if (tri_walks) {
           ws.cursor = A->ctl(level, 5 + 3 * g);
           ws.ray_count = nullptr;
           ws.last_stage = 1;
-          HIP_TRY(rt::launch_walk(sd, ws, true, true, kBounceBlocks, ws_stream));
+          HIP_TRY(rt::launch_walk(sd, ws, true, true, S->walk_blocks, ws_stream));
         }
         if (fork) {
           HIP_TRY(hipEventRecord(S->ev_join[par], side));

@@ -152,6 +152,9 @@ hipError_t launch_trace(const SceneDev &sc, const TraceArgs &t, int blocks, hipS
 // Blocks of k_trace that can be resident at once on the current device (what a
 // launch should use: a block that waits for a free slot finds nothing left to do).
 int trace_resident_blocks();
+// The same for k_walk, as a multiple of QUEUE_SEGMENTS (a walking wave takes items
+// from every segment, so more blocks than fit at once only shorten each wave's share).
+int walk_resident_blocks();
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st);
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
                           hipStream_t st);

@@ -665,6 +665,18 @@ int trace_resident_blocks() {
   return per_cu * cus;
 }
 
+int walk_resident_blocks() {
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_walk<false, true>, 256, 0) !=
+          hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      per_cu <= 0 || cus <= 0)
+    return 1024;
+  const int blocks = per_cu * cus / QUEUE_SEGMENTS * QUEUE_SEGMENTS;
+  return blocks > 0 ? blocks : QUEUE_SEGMENTS;
+}
+
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, st, sc, s);
   return hipGetLastError();

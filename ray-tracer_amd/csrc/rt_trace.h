@@ -445,9 +445,13 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
             // hand out (lanes it could not serve are served at the next refill), or
             // nothing is left.  The lanes look at 64 segments at a time; a cursor
             // read here may be behind, which only costs a useless attempt later.
+            // (every wave starts its search somewhere else: waves that all went to the
+            // next segment would use it up together and move on as a crowd, all on
+            // one cursor)
             bool found = false;
+            const uint32_t hop = 1u + (uint32_t)(wave_id * 37u) % (QUEUE_SEGMENTS - 1);
             for (uint32_t round = 0; round < QUEUE_SEGMENTS / 64 && !found; round++) {
-              const uint32_t s = (seg + 1 + round * 64 + (uint32_t)lane) % QUEUE_SEGMENTS;
+              const uint32_t s = (seg + hop + round * 64 + (uint32_t)lane) % QUEUE_SEGMENTS;
               uint32_t n = t.in.count[s * CTL_WORDS];
               if (n > t.in.seg_capacity)
                 n = t.in.seg_capacity;

@@ -90,6 +90,7 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
 }
 
 constexpr int PARK_SLOTS = 8; // parked leaves per lane (rt_walk.h, k_walk)
+static_assert(QUEUE_SEGMENTS % 64 == 0, "a wave looks for work in 64 segments at a time");
 
 // The discriminant screen of maths.cpp:132-133 for leaf slot `slot`: can the
 // exact test pass at all?  (The same b, c, products and comparison as
@@ -135,6 +136,11 @@ __device__ __forceinline__ bool leaf_screen(const SceneDev &sc, int slot, float 
 // [9] lanes with a ray, summed over the visits
 __device__ unsigned long long g_stamps[16];
 #define RT_STAMP() __builtin_amdgcn_s_memtime()
+#ifdef RT_STAMPS_TRI // the same for the nearest-hit walk over the triangles
+constexpr bool STAMPS_OF_TRI = true;
+#else
+constexpr bool STAMPS_OF_TRI = false;
+#endif
 #endif
 
 template <bool ANY_HIT, bool TRI>
@@ -145,18 +151,21 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
   unsigned long long n_over = 0, n_busy = 0;
   const unsigned long long st_begin = RT_STAMP();
 #endif
-  // this block serves segment (block % n_seg) of the queue together with the
-  // other blocks of that residue; they share the segment's cursor
-  const uint32_t seg = my_segment();
+  // The block starts on segment (block % n_seg) of the queue and moves on to the
+  // other segments when that one is used up (the cursors are atomics, the lengths
+  // were written before this launch): a wave that stayed with one segment spent
+  // the end of every launch on the longest walks of that segment's last rays, and
+  // the nearest-hit walk over a million triangles ran with 25 of 64 lanes walking.
+  uint32_t seg = my_segment();
   uint32_t n_in = w.in.count[seg * CTL_WORDS];
   if (n_in > w.in.seg_capacity)
     n_in = w.in.seg_capacity;
-  const size_t seg_base = (size_t)seg * w.in.seg_capacity;
-  uint32_t *const cursor = w.cursor + seg * CTL_WORDS;
+  size_t seg_base = (size_t)seg * w.in.seg_capacity;
+  uint32_t *cursor = w.cursor + seg * CTL_WORDS;
 
   enum { EMPTY = 0, BUSY = 1, DRAIN = 2 }; // DRAIN: walk over, parked leaves left
   int state = EMPTY;
-  uint32_t ray = 0, tagA = 0, tagB = 0;
+  uint32_t ray = 0, tagA = 0, tagB = 0; // ray: the item's slot in the whole queue
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, a = 0, a4 = 0, da = 0, ol = 0;
   float ix = 0, iy = 0, iz = 0; // spheres: 1/d per axis; `da` then holds >= 1/|d|
   float len_s = RT_INF, bound = RT_INF;
@@ -224,13 +233,13 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
         if (ANY_HIT) {
           if (!w.last_stage) {
             if (idx_s >= 0) // blocked: cancel the item for the walk that follows
-              w.in.items[2 * (seg_base + ray) + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+              w.in.items[2 * (size_t)ray + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
           } else if (idx_s < 0) { // unoccluded: renderer.cpp:119-127, as an integer sum
             add_light(w.extra, tagA, tagB);
           }
         } else {
-          w.hits.rec[seg_base + ray] = make_float4(sPx, sPy, sPz, len_s);
-          w.hits.idx[seg_base + ray] = idx_s;
+          w.hits.rec[ray] = make_float4(sPx, sPy, sPz, len_s);
+          w.hits.idx[ray] = idx_s;
         }
         state = EMPTY;
       }
@@ -247,18 +256,52 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
           if (lane == leader)
             base = atomicAdd(cursor, (uint32_t)n_e);
           base = __builtin_amdgcn_readlane(base, leader);
-          if (base + (uint32_t)n_e >= n_in)
-            drained = true;
+          const size_t here = seg_base;
+          const uint32_t n_here = n_in;
+          if (base + (uint32_t)n_e >= n_in) {
+            // This segment is used up: on to the next one that still has items to
+            // hand out (lanes it could not serve are served at the next refill), or
+            // nothing is left.  The lanes look at 64 segments at a time; a cursor
+            // read here may be behind, which only costs a useless attempt later.
+            // (every wave starts its search somewhere else: waves that all went to the
+            // next segment would use that one up together and move on as a crowd, all
+            // on one cursor)
+            bool found = false;
+            const uint32_t hop = 1u + (uint32_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) * 37u) %
+                                          (QUEUE_SEGMENTS - 1);
+            for (uint32_t round = 0; round < QUEUE_SEGMENTS / 64 && !found; round++) {
+              const uint32_t s = (seg + hop + round * 64 + (uint32_t)lane) % QUEUE_SEGMENTS;
+              uint32_t n = w.in.count[s * CTL_WORDS];
+              if (n > w.in.seg_capacity)
+                n = w.in.seg_capacity;
+              const uint32_t c = __hip_atomic_load(w.cursor + s * CTL_WORDS, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned long long m = __ballot(c < n);
+              if (m != 0) {
+                const int first = __builtin_ctzll(m);
+                seg = (uint32_t)__builtin_amdgcn_readlane((int)s, first);
+                n_in = (uint32_t)__builtin_amdgcn_readlane((int)n, first);
+                found = true;
+              }
+            }
+            if (found) {
+              seg_base = (size_t)seg * w.in.seg_capacity;
+              cursor = w.cursor + seg * CTL_WORDS;
+            } else {
+              drained = true;
+            }
+          }
           if (state == EMPTY) {
             const uint32_t r = base + (uint32_t)__builtin_popcountll(e & ((1ull << lane) - 1ull));
-            if (r < n_in) {
+            if (r < n_here) {
+              const size_t seg_base = here; // of the segment this item came from
               const float4 qa = w.in.items[2 * (seg_base + r)],
                            qb = w.in.items[2 * (seg_base + r) + 1];
 #ifdef RT_STAMPS
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               st_f1 = RT_STAMP();
 #endif
-              ray = r;
+              ray = (uint32_t)(seg_base + r);
               ox = qa.x;
               oy = qa.y;
               oz = qa.z;
@@ -358,6 +401,7 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
     const unsigned long long st_c = RT_STAMP();
     unsigned long long st_d = st_c;
     int st_over = 0;
+    n_busy += __builtin_popcountll(__ballot(state == BUSY));
 #endif
     if (state == BUSY) {
       // ---- one node visit: the bounds of its (up to four) children ----
@@ -368,6 +412,10 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
       bool touch[BVH_WIDTH];
       if (TRI) {
         const TriNode N = sc.tbvh[node];
+#ifdef RT_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_d = RT_STAMP();
+#endif
 #pragma unroll
         for (int c = 0; c < BVH_WIDTH; c++) {
           links[c] = N.link[c];
@@ -435,12 +483,11 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
       n_visit++;
       if (__any(st_over))
         n_over++;
-      n_busy += __builtin_popcountll(__ballot(state == BUSY || state == DRAIN));
     }
 #endif
   }
 #ifdef RT_STAMPS
-  if (!ANY_HIT && !TRI && lane == 0) {
+  if (!ANY_HIT && TRI == STAMPS_OF_TRI && lane == 0) {
     atomicAdd(&g_stamps[0], RT_STAMP() - st_begin);
     atomicAdd(&g_stamps[1], st_serv);
     atomicAdd(&g_stamps[2], st_load);

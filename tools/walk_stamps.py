@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(REPO, "ray-tracer_amd", "python"))
 sys.path.insert(0, REPO)
 import torch  # noqa: E402
 import rtamd  # noqa: E402
-rtamd.LIB_PATH = os.path.join(REPO, "build", "librt_amd_stamps.so")
+rtamd.LIB_PATH = os.path.join(REPO, "build", os.environ.get("STAMPS_LIB", "librt_amd_stamps.so"))
 import bench  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "10k-spheres-4k-depth8"
 sc, w, h, depth = bench.build_scene(name)
