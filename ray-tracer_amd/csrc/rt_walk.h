@@ -90,6 +90,7 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
 }
 
 constexpr int PARK_SLOTS = 8; // parked leaves per lane (rt_walk.h, k_walk)
+constexpr int WALK_SHARE_AT = 16; // idle lanes at which walks in progress are shared out
 static_assert(QUEUE_SEGMENTS % 64 == 0, "a wave looks for work in 64 segments at a time");
 
 // The discriminant screen of maths.cpp:132-133 for leaf slot `slot`: can the
@@ -163,8 +164,22 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
   size_t seg_base = (size_t)seg * w.in.seg_capacity;
   uint32_t *cursor = w.cursor + seg * CTL_WORDS;
 
-  enum { EMPTY = 0, BUSY = 1, DRAIN = 2 }; // DRAIN: walk over, parked leaves left
+  // DRAIN: walk over, parked leaves left.  OVER: those tested too; the lane waits
+  // for the lanes that took over parts of its walk, if any.  REPORT: see below.
+  enum { EMPTY = 0, BUSY = 1, DRAIN = 2, OVER = 3, REPORT = 4 };
   int state = EMPTY;
+  // Sharing a walk.  Once the queue is used up, a lane with nothing to do takes the
+  // oldest entry off the stack of a lane that is still walking (the subtree nearest
+  // the root) and walks it for that lane's ray: `owner` is the lane it took it from,
+  // `n_help` counts the lanes that have taken from this one and not yet reported.
+  // A helper's nearest hit is folded into its owner's by the same order-free rule
+  // (smallest |P|, lowest index on ties), so the result is that of the undivided
+  // walk; its bound is the owner's at the time, which can only be looser.  Without
+  // this the end of every launch belonged to the few longest walks of the level: a
+  // grazing ray over a million-triangle height field visits hundreds of nodes, and
+  // the waves of the nearest-hit triangle walk had 25 of 64 lanes walking.
+  int owner = -1, n_help = 0;
+  __shared__ int pair_words[256]; // per wave: the lanes to take from, by rank
   uint32_t ray = 0, tagA = 0, tagB = 0; // ray: the item's slot in the whole queue
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, a = 0, a4 = 0, da = 0, ol = 0;
   float ix = 0, iy = 0, iz = 0; // spheres: 1/d per axis; `da` then holds >= 1/|d|
@@ -190,7 +205,9 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
 
   while (true) {
     const int n_free = __builtin_popcountll(__ballot(state != BUSY));
-    if (n_free == 64 || (!drained && n_free >= w.fetch_at)) {
+    if (n_free == 64 || (!drained && n_free >= w.fetch_at) ||
+        (drained && __builtin_popcountll(__ballot(state == EMPTY || state == DRAIN)) >= WALK_SHARE_AT &&
+         __any(state == BUSY && sp >= 1))) {
 #ifdef RT_STAMPS
       const unsigned long long st_a = RT_STAMP();
       unsigned long long st_f0 = st_a, st_f1 = st_a;
@@ -228,8 +245,41 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
           }
         }
       }
+      // ---- walks that are over: helpers report to the lane whose ray they share ----
+      if (state == DRAIN)
+        state = OVER;
+      while (true) {
+        if (state == OVER && n_help == 0 && owner >= 0)
+          state = REPORT;
+        const unsigned long long m = __ballot(state == REPORT);
+        if (!m)
+          break;
+        for (unsigned long long rest = m; rest; rest &= rest - 1) {
+          const int h = __builtin_ctzll(rest);
+          const int o = __builtin_amdgcn_readlane(owner, h);
+          const float hl = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(len_s), h));
+          const int hi = __builtin_amdgcn_readlane(idx_s, h);
+          const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sPx), h)),
+                      hy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sPy), h)),
+                      hz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sPz), h));
+          if (lane == o) {
+            if (hi >= 0 && (idx_s < 0 || hl < len_s || (hl == len_s && hi < idx_s))) {
+              len_s = hl;
+              idx_s = hi;
+              sPx = hx;
+              sPy = hy;
+              sPz = hz;
+            }
+            n_help--;
+          }
+        }
+        if (state == REPORT) {
+          state = EMPTY;
+          owner = -1;
+        }
+      }
       // ---- hand in finished items ----
-      if (state == DRAIN) {
+      if (state == OVER && n_help == 0) {
         if (ANY_HIT) {
           if (!w.last_stage) {
             if (idx_s >= 0) // blocked: cancel the item for the walk that follows
@@ -383,6 +433,63 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
                 }
               }
             }
+          }
+        }
+      }
+      // ---- nothing left to fetch: idle lanes take over parts of the walks in progress ----
+      if (drained) {
+        const unsigned long long th = __ballot(state == EMPTY);
+        const unsigned long long vi = __ballot(state == BUSY && sp >= 1);
+        if (th != 0 && vi != 0) {
+          const int wave_base = (int)(threadIdx.x & ~63u);
+          const unsigned long long lt = (1ull << lane) - 1ull;
+          const int my_v = __builtin_popcountll(vi & lt), my_t = __builtin_popcountll(th & lt);
+          const bool robbed = state == BUSY && sp >= 1 && my_v < __builtin_popcountll(th);
+          const bool thief = state == EMPTY && my_t < __builtin_popcountll(vi);
+          if (robbed)
+            pair_words[wave_base + my_v] = lane;
+          __builtin_amdgcn_wave_barrier();
+          int v = lane;
+          if (thief)
+            v = pair_words[wave_base + my_t];
+          const float vox = __shfl(ox, v), voy = __shfl(oy, v), voz = __shfl(oz, v);
+          const float vdx = __shfl(dx, v), vdy = __shfl(dy, v), vdz = __shfl(dz, v);
+          const float va = __shfl(a, v), va4 = __shfl(a4, v), vda = __shfl(da, v), vol = __shfl(ol, v);
+          const float vix = __shfl(ix, v), viy = __shfl(iy, v), viz = __shfl(iz, v);
+          const float vbound = __shfl(bound, v);
+          int taken = 0;
+          if (thief)
+            taken = stack_words[wave_base + v]; // the oldest entry of that lane's stack
+          __builtin_amdgcn_wave_barrier();
+          if (robbed) {
+            const int top = stack.pop(sp);
+            if (sp > 0)
+              stack.lds[0] = top;
+            n_help++;
+          }
+          if (thief) {
+            ox = vox;
+            oy = voy;
+            oz = voz;
+            dx = vdx;
+            dy = vdy;
+            dz = vdz;
+            a = va;
+            a4 = va4;
+            da = vda;
+            ol = vol;
+            ix = vix;
+            iy = viy;
+            iz = viz;
+            bound = vbound;
+            owner = v;
+            n_help = 0;
+            len_s = RT_INF;
+            idx_s = -1;
+            sp = 0;
+            n_park = 0;
+            node = taken;
+            state = BUSY;
           }
         }
       }
