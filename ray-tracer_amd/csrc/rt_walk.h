@@ -89,8 +89,15 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
   return false;
 }
 
+// Lanes of one wave hand words to each other through LDS: the hardware runs a
+// wave's LDS instructions in order, but a thread never reads what it wrote itself
+// here, so nothing tells the compiler to keep the order; this does (and waits).
+#define RT_WAVE_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 constexpr int PARK_SLOTS = 8; // parked leaves per lane (rt_walk.h, k_walk)
-constexpr int WALK_SHARE_AT = 16; // idle lanes at which walks in progress are shared out
+#ifndef WALK_SHARE_AT_V
+#define WALK_SHARE_AT_V 16
+#endif
+constexpr int WALK_SHARE_AT = WALK_SHARE_AT_V; // idle lanes at which walks in progress are shared out
 static_assert(QUEUE_SEGMENTS % 64 == 0, "a wave looks for work in 64 segments at a time");
 
 // The discriminant screen of maths.cpp:132-133 for leaf slot `slot`: can the
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
           const bool thief = state == EMPTY && my_t < __builtin_popcountll(vi);
           if (robbed)
             pair_words[wave_base + my_v] = lane;
-          __builtin_amdgcn_wave_barrier();
+          RT_WAVE_SYNC_LDS();
           int v = lane;
           if (thief)
             v = pair_words[wave_base + my_t];
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
           int taken = 0;
           if (thief)
             taken = stack_words[wave_base + v]; // the oldest entry of that lane's stack
-          __builtin_amdgcn_wave_barrier();
+          RT_WAVE_SYNC_LDS();
           if (robbed) {
             const int top = stack.pop(sp);
             if (sp > 0)
