@@ -756,7 +756,8 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
     HIP_TRY(rt::launch_trace(sd, ta, P.trace_blocks, st)); // <= A->have.trace_waves / 4
     if (S->timing)
       HIP_TRY(hipEventRecord(S->ev_t[2], st));
-    HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, (size_t)fr->w * fr->h, st));
+    HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, fr->w, fr->h, P.band_rows,
+                               P.band_count == 1 ? 0 : fr->band_index, P.band_count, st));
     if (S->timing) {
       HIP_TRY(hipEventRecord(S->ev_t[3], st));
       S->timed_stages = 3;
@@ -857,7 +858,8 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
       HIP_TRY(hipStreamWaitEvent(st, S->ev_join[k], 0));
   if (S->timing)
     HIP_TRY(hipEventRecord(S->ev_t[2], st));
-  HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, (size_t)fr->w * fr->h, st));
+  HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, fr->w, fr->h, P.band_rows,
+                               P.band_count == 1 ? 0 : fr->band_index, P.band_count, st));
   if (S->timing) {
     HIP_TRY(hipEventRecord(S->ev_t[3], st));
     S->timed_stages = 3;

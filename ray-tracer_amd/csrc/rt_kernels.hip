@@ -505,22 +505,31 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
 
 // Pixel = saturating sum of the primary hit's light (already in fb) and the
 // integer side sums of all bounce hits; the side sums are cleared for reuse.
-__global__ void k_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels) {
-  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_pixels)
+// One thread per pixel of the bands this frame owns (bands of band_rows rows, band
+// b belongs to share b % band_count): the other ranks' rows have no sums here.
+__global__ void k_compose(uint8_t *fb, unsigned long long *extra, int w, int h, int band_rows,
+                          int band_index, int band_count, int owned_rows) {
+  const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (x >= w)
     return;
-  const unsigned long long e = extra[p];
-  if (e == 0)
-    return;
-  const uint32_t e0 = (uint32_t)(e & 0x1fffffu), e1 = (uint32_t)((e >> 21) & 0x1fffffu),
-                 e2 = (uint32_t)((e >> 42) & 0x1fffffu);
-  uchar4 c = reinterpret_cast<uchar4 *>(fb)[p];
-  uint32_t v0 = c.x + e0, v1 = c.y + e1, v2 = c.z + e2;
-  c.x = (unsigned char)(v0 > 255u ? 255u : v0);
-  c.y = (unsigned char)(v1 > 255u ? 255u : v1);
-  c.z = (unsigned char)(v2 > 255u ? 255u : v2);
-  reinterpret_cast<uchar4 *>(fb)[p] = c;
-  extra[p] = 0;
+  for (int r_owned = (int)blockIdx.y; r_owned < owned_rows; r_owned += (int)gridDim.y) {
+    const int row = ((r_owned / band_rows) * band_count + band_index) * band_rows + r_owned % band_rows;
+    if (row >= h)
+      return;
+    const size_t p = (size_t)row * (size_t)w + (size_t)x;
+    const unsigned long long e = extra[p];
+    if (e == 0)
+      continue;
+    const uint32_t e0 = (uint32_t)(e & 0x1fffffu), e1 = (uint32_t)((e >> 21) & 0x1fffffu),
+                   e2 = (uint32_t)((e >> 42) & 0x1fffffu);
+    uchar4 c = reinterpret_cast<uchar4 *>(fb)[p];
+    uint32_t v0 = c.x + e0, v1 = c.y + e1, v2 = c.z + e2;
+    c.x = (unsigned char)(v0 > 255u ? 255u : v0);
+    c.y = (unsigned char)(v1 > 255u ? 255u : v1);
+    c.z = (unsigned char)(v2 > 255u ? 255u : v2);
+    reinterpret_cast<uchar4 *>(fb)[p] = c;
+    extra[p] = 0;
+  }
 }
 
 } // namespace rt
@@ -705,10 +714,19 @@ hipError_t launch_sum_rays(uint64_t *parts, uint64_t *total, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, size_t n_pixels,
-                          hipStream_t st) {
-  hipLaunchKernelGGL(k_compose, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0,
-                     st, fb, extra, n_pixels);
+hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, int w, int h, int band_rows,
+                          int band_index, int band_count, hipStream_t st) {
+  if (w <= 0 || h <= 0 || band_rows <= 0 || band_count <= 0 || band_index < 0 ||
+      band_index >= band_count)
+    return hipErrorInvalidValue;
+  const int n_bands = (h + band_rows - 1) / band_rows;
+  const int owned = n_bands > band_index ? (n_bands - band_index + band_count - 1) / band_count : 0;
+  const long owned_rows = (long)owned * band_rows;
+  if (owned_rows == 0)
+    return hipSuccess;
+  const dim3 grid((unsigned)((w + 255) / 256), (unsigned)(owned_rows < 65535 ? owned_rows : 65535));
+  hipLaunchKernelGGL(k_compose, grid, dim3(256), 0, st, fb, extra, w, h, band_rows, band_index,
+                     band_count, (int)owned_rows);
   return hipGetLastError();
 }
 
