@@ -1,5 +1,6 @@
 """The reference's own main.cpp, unmodified, links against librt_shim.so in
-place of renderer.cpp + maths.cpp, exactly as INTEGRATION.md section 1 says.
+place of renderer.cpp + maths.cpp: g++ main.cpp -lrt_shim, nothing else changed
+(main.cpp:104-106 calls render(), renderer.hpp:16-23 declares both functions).
 Build-container test: needs /root/reference (absent on the GPU box) and g++.
 Nothing is run: the run-time check of the shim's symbols is the GPU test
 test_gpu_parity.py::test_reference_signature_shim."""
