@@ -94,10 +94,7 @@ __device__ __forceinline__ bool leaf_test(const SceneDev &sc, int slot, float a,
 // here, so nothing tells the compiler to keep the order; this does (and waits).
 #define RT_WAVE_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 constexpr int PARK_SLOTS = 8; // parked leaves per lane (rt_walk.h, k_walk)
-#ifndef WALK_SHARE_AT_V
-#define WALK_SHARE_AT_V 16
-#endif
-constexpr int WALK_SHARE_AT = WALK_SHARE_AT_V; // idle lanes at which walks in progress are shared out
+constexpr int WALK_SHARE_AT = 16; // idle lanes at which walks in progress are shared out
 static_assert(QUEUE_SEGMENTS % 64 == 0, "a wave looks for work in 64 segments at a time");
 
 // The discriminant screen of maths.cpp:132-133 for leaf slot `slot`: can the
