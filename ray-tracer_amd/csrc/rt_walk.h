@@ -138,7 +138,7 @@ __device__ __forceinline__ bool leaf_screen(const SceneDev &sc, int slot, float 
 // load's issue to its data, [3] rest of the visits, [4] service phases, [5] visits,
 // [6] waves, [7] of the service time: waiting for the cursor atomic and the items,
 // [8] visits in which some lane tested a leaf on the spot (four already parked),
-// [9] lanes with a ray, summed over the visits
+// [9] lanes with a ray, summed over the visits, [10] of the service phases: testing parked leaves
 __device__ unsigned long long g_stamps[16];
 #define RT_STAMP() __builtin_amdgcn_s_memtime()
 #ifdef RT_STAMPS_TRI // the same for the nearest-hit walk over the triangles
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
   const int lane = threadIdx.x & 63;
 #ifdef RT_STAMPS
   unsigned long long st_serv = 0, st_load = 0, st_visit = 0, st_fetch = 0, n_serv = 0, n_visit = 0;
-  unsigned long long n_over = 0, n_busy = 0;
+  unsigned long long n_over = 0, n_busy = 0, st_work = 0;
   const unsigned long long st_begin = RT_STAMP();
 #endif
   // The block starts on segment (block % n_seg) of the queue and moves on to the
@@ -249,6 +249,9 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
           }
         }
       }
+#ifdef RT_STAMPS
+      st_work += RT_STAMP() - st_a;
+#endif
       // ---- walks that are over: helpers report to the lane whose ray they share ----
       if (state == DRAIN)
         state = OVER;
@@ -609,6 +612,7 @@ __global__ __launch_bounds__(256, 5) void k_walk(SceneDev sc, WalkArgs w) {
     atomicAdd(&g_stamps[7], st_fetch);
     atomicAdd(&g_stamps[8], n_over);
     atomicAdd(&g_stamps[9], n_busy);
+    atomicAdd(&g_stamps[10], st_work);
   }
 #endif
   add_ray_count(w.ray_count, n_rays);

@@ -31,3 +31,4 @@ print(f"cycles per wave: total {v[0]/waves:.0f}  service {v[1]/waves:.0f}  node-
 print(f"service phases {v[4]/waves:.1f} per wave, {v[1]/max(1,v[4]):.0f} cycles each, of which cursor+item wait {v[7]/max(1,v[4]):.0f}")
 print(f"visits {v[5]/waves:.1f} per wave, load wait {v[2]/max(1,v[5]):.0f} + other {v[3]/max(1,v[5]):.0f} cycles each")
 print(f"visits with an on-the-spot leaf test: {100.0 * v[8] / max(1, v[5]):.1f} %; lanes with a ray per visit {v[9] / max(1, v[5]):.1f}")
+print(f"of the service time, testing parked leaves: {100.0 * v[10] / max(1, v[1]):.0f} %")
