@@ -705,10 +705,14 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
   if (P.bounces) {
     // only the levels this frame can reach, and the overflow flag
     const int used_levels = A->have.trace ? 3 : fr->max_depth + 2;
-    HIP_TRY(hipMemsetAsync(A->counts, 0,
-                           (size_t)used_levels * A->have.ctl_rows * kRowWords * sizeof(uint32_t),
-                           st));
-    HIP_TRY(hipMemsetAsync(A->overflow_flag(), 0, sizeof(uint32_t), st));
+    const size_t row_bytes = (size_t)used_levels * A->have.ctl_rows * kRowWords * sizeof(uint32_t);
+    if (used_levels == A->have.levels) {
+      // the flag is the word behind the last row (and the region is padded to 256 bytes)
+      HIP_TRY(hipMemsetAsync(A->counts, 0, row_bytes + 16, st));
+    } else {
+      HIP_TRY(hipMemsetAsync(A->counts, 0, row_bytes, st));
+      HIP_TRY(hipMemsetAsync(A->overflow_flag(), 0, sizeof(uint32_t), st));
+    }
     bd.max_depth = fr->max_depth;
     bd.extra = A->extra;
     bd.out = A->queue_for_level(2);
