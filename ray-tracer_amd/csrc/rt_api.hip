@@ -669,16 +669,19 @@ static int plan_frame(const rt_scene *S, const camera *cam, const rt_frame *fr, 
 // null to keep everything on the caller's stream.
 static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t side,
                                  const camera *cam, const rt_frame *fr, const FramePlan &P,
-                                 uint64_t *dev_ray_count, uint64_t *dev_verify);
+                                 uint64_t *dev_ray_count, uint64_t *dev_verify,
+                                 uint64_t *ray_total, bool *summed);
 
 // The kernels count rays in the scene's partial counters; the caller's word gets
 // their sum at the end of the frame.
 static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, const camera *cam,
                         const rt_frame *fr, const FramePlan &P, uint64_t *dev_ray_count,
                         uint64_t *dev_verify) {
+  bool summed = false; // the last kernel of a frame with bounces does the sum itself
   const int rc = render_frame_launches(S, A, side, cam, fr, P,
-                                       dev_ray_count ? S->ray_parts.p : nullptr, dev_verify);
-  if (rc != RT_OK || !dev_ray_count)
+                                       dev_ray_count ? S->ray_parts.p : nullptr, dev_verify,
+                                       dev_ray_count, &summed);
+  if (rc != RT_OK || !dev_ray_count || summed)
     return rc;
   HIP_TRY(rt::launch_sum_rays(S->ray_parts.p, dev_ray_count, (hipStream_t)fr->stream));
   return RT_OK;
@@ -686,7 +689,8 @@ static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, con
 
 static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t side,
                                  const camera *cam, const rt_frame *fr, const FramePlan &P,
-                                 uint64_t *dev_ray_count, uint64_t *dev_verify) {
+                                 uint64_t *dev_ray_count, uint64_t *dev_verify,
+                                 uint64_t *ray_total, bool *summed) {
   hipStream_t st = (hipStream_t)fr->stream;
   rt::FrameDev f;
   f.fb = fr->dev_fb;
@@ -761,7 +765,9 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
     if (S->timing)
       HIP_TRY(hipEventRecord(S->ev_t[2], st));
     HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, fr->w, fr->h, P.band_rows,
-                               P.band_count == 1 ? 0 : fr->band_index, P.band_count, st));
+                               P.band_count == 1 ? 0 : fr->band_index, P.band_count,
+                               dev_ray_count, dev_ray_count ? ray_total : nullptr, st));
+    *summed = dev_ray_count != nullptr;
     if (S->timing) {
       HIP_TRY(hipEventRecord(S->ev_t[3], st));
       S->timed_stages = 3;
@@ -863,7 +869,9 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
   if (S->timing)
     HIP_TRY(hipEventRecord(S->ev_t[2], st));
   HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, fr->w, fr->h, P.band_rows,
-                               P.band_count == 1 ? 0 : fr->band_index, P.band_count, st));
+                               P.band_count == 1 ? 0 : fr->band_index, P.band_count,
+                               dev_ray_count, dev_ray_count ? ray_total : nullptr, st));
+  *summed = dev_ray_count != nullptr;
   if (S->timing) {
     HIP_TRY(hipEventRecord(S->ev_t[3], st));
     S->timed_stages = 3;

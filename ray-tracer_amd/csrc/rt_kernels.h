@@ -157,8 +157,10 @@ int trace_resident_blocks();
 int walk_resident_blocks();
 hipError_t launch_shade(const SceneDev &sc, const ShadeArgs &s, int blocks, hipStream_t st);
 // over the pixels of the bands the frame owns (band b belongs to share b % band_count)
+// parts / total (or null): the first block also does what launch_sum_rays does
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, int w, int h, int band_rows,
-                          int band_index, int band_count, hipStream_t st);
+                          int band_index, int band_count, uint64_t *parts, uint64_t *total,
+                          hipStream_t st);
 hipError_t launch_sum_rays(uint64_t *parts, uint64_t *total, hipStream_t st);
 hipError_t launch_gather_leaves(const float4 *sph_geo, const uchar4 *col_sph,
                                 const float4 *mat_sph, const int32_t *leaf_idx, float4 *leaf_geo,

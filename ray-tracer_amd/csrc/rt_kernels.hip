@@ -507,8 +507,22 @@ __global__ __launch_bounds__(256) void k_bounce(SceneDev sc, BounceDev bd,
 // integer side sums of all bounce hits; the side sums are cleared for reuse.
 // One thread per pixel of the bands this frame owns (bands of band_rows rows, band
 // b belongs to share b % band_count): the other ranks' rows have no sums here.
+// The first block also folds the frame's partial ray counters into the caller's word,
+// as k_sum_rays does (parts may be null; RAY_PARTS threads per block).
 __global__ void k_compose(uint8_t *fb, unsigned long long *extra, int w, int h, int band_rows,
-                          int band_index, int band_count, int owned_rows) {
+                          int band_index, int band_count, int owned_rows, uint64_t *parts,
+                          uint64_t *total) {
+  if (parts != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+    unsigned long long *p =
+        reinterpret_cast<unsigned long long *>(parts) + threadIdx.x * RAY_PART_STRIDE;
+    unsigned long long v = *p;
+    *p = 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v)
+      atomicAdd(reinterpret_cast<unsigned long long *>(total), v);
+  }
   const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (x >= w)
     return;
@@ -714,8 +728,10 @@ hipError_t launch_sum_rays(uint64_t *parts, uint64_t *total, hipStream_t st) {
   return hipGetLastError();
 }
 
+static_assert(RAY_PARTS == 256, "k_compose sums the partial counters with one block of 256");
 hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, int w, int h, int band_rows,
-                          int band_index, int band_count, hipStream_t st) {
+                          int band_index, int band_count, uint64_t *parts, uint64_t *total,
+                          hipStream_t st) {
   if (w <= 0 || h <= 0 || band_rows <= 0 || band_count <= 0 || band_index < 0 ||
       band_index >= band_count)
     return hipErrorInvalidValue;
@@ -723,10 +739,10 @@ hipError_t launch_compose(uint8_t *fb, unsigned long long *extra, int w, int h, 
   const int owned = n_bands > band_index ? (n_bands - band_index + band_count - 1) / band_count : 0;
   const long owned_rows = (long)owned * band_rows;
   if (owned_rows == 0)
-    return hipSuccess;
+    return parts ? launch_sum_rays(parts, total, st) : hipSuccess;
   const dim3 grid((unsigned)((w + 255) / 256), (unsigned)(owned_rows < 65535 ? owned_rows : 65535));
   hipLaunchKernelGGL(k_compose, grid, dim3(256), 0, st, fb, extra, w, h, band_rows, band_index,
-                     band_count, (int)owned_rows);
+                     band_count, (int)owned_rows, parts, total);
   return hipGetLastError();
 }
 
