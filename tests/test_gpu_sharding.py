@@ -95,3 +95,33 @@ def test_eight_way_split_of_the_4k_depth8_frame():
     assert sum(shares) == n_whole
     assert max(shares) < 1.1 * n_whole / world      # the interleaved bands balance the ranks
     assert torch.equal(whole, parts)
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_more_ranks_than_bands_and_a_ragged_last_band(depth):
+    """A 200x20 frame in bands of 8 rows has three bands, the last of four rows; split
+    over five ranks, two of them own nothing.  The ranks' frames together are the
+    whole frame, their ray counts add up, and an empty share counts no ray."""
+    import torch
+    import rtamd
+    sc = rtamd.material_grid_scene(12, 12)
+    w, h, world = 200, 20, 5
+    dev = torch.device("cuda", 0)
+    whole = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    parts = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    with rtamd.DeviceScene(sc) as ds:
+        ds.render_device(whole.data_ptr(), None, w, h, max_depth=depth, dev_ray_count=cnt.data_ptr())
+        torch.cuda.synchronize()
+        n_whole = int(cnt.item())
+        shares = []
+        for rank in range(world):
+            cnt.zero_()
+            ds.render_device(parts.data_ptr(), None, w, h, max_depth=depth, band_rows=8,
+                             band_index=rank, band_count=world, dev_ray_count=cnt.data_ptr())
+            torch.cuda.synchronize()
+            assert not ds.queue_overflowed()
+            shares.append(int(cnt.item()))
+    assert shares[3] == 0 and shares[4] == 0 and min(shares[:3]) > 0
+    assert sum(shares) == n_whole
+    assert torch.equal(whole, parts)
