@@ -56,46 +56,71 @@ def build_scene(name):
     return sc, w, h, depth
 
 
-def cpu_baseline(sc, w, h, depth, budget_s=20.0):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sc, w, h, depth, budget_s=24.0):
     """Times the CPU oracle (oracle/, the bit-exact restatement of the reference
-    renderer) on evenly spaced rows of the same frame, sized to ~budget_s."""
+    renderer) on a bounded sample of the same frame: one warm-up run, then three
+    timed runs of the same sample, the median reported.  The sample is sized so
+    that the four runs take about budget_s together."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from oracle_py import Oracle
     o = Oracle()
     threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    per_run = budget_s / 4.0
+    build = "oracle/rt_oracle.c, gcc -O2 -fopenmp -ffp-contract=off, schedule(dynamic) over rows"
     if sc.t_size > PLAIN_LOOP_MAX_PRIMS:
         # a single row of this frame takes the CPU minutes: sample pixels instead
         rng = np.random.RandomState(2024)
-        def sample(n):
-            px = np.stack([rng.randint(0, h, n), rng.randint(0, w, n)], 1)
+        def pixels(n):
+            return np.stack([rng.randint(0, h, n), rng.randint(0, w, n)], 1)
+        def run(px):
             t = time.perf_counter()
             _, _, rays = o.render_pixels(sc, w, h, depth, px)
             return rays, time.perf_counter() - t
-        r0, dt0 = sample(4 * threads)
-        n = int(max(4 * threads, min(200000, 4 * threads * budget_s / max(dt0, 1e-3))))
-        rays, dt = sample(n)
-        return {
-            "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{n} random pixels ({rays} rays, {dt:.1f} s) of the same {w}x{h} frame; "
-                      f"oracle/rt_oracle.c, gcc -O2 -fopenmp -ffp-contract=off",
-        }
-    # calibrate on a sparse sample, then size the real one
-    step0 = max(1, h // 32)
-    t = time.perf_counter()
-    _, _, n0 = o.render(sc, w, h, depth, rows=(step0 // 2, h, step0), want_ids=False)
-    dt0 = time.perf_counter() - t
-    rows0 = len(range(step0 // 2, h, step0))
-    per_row = dt0 / rows0
-    want_rows = int(min(h, max(rows0, budget_s / per_row)))
-    step = max(1, h // want_rows)
-    t = time.perf_counter()
-    _, _, n = o.render(sc, w, h, depth, rows=(step // 2, h, step), want_ids=False)
-    dt = time.perf_counter() - t
-    rows = len(range(step // 2, h, step))
+        _, dt0 = run(pixels(4 * threads))          # calibration
+        n = int(max(4 * threads, min(200000, 4 * threads * per_run / max(dt0, 1e-3))))
+        px = pixels(n)
+        run(px)                                    # warm-up
+        runs = [run(px) for _ in range(3)]
+        rays = runs[0][0]
+        times = sorted(dt for _, dt in runs)
+        what = f"{n} random pixels ({rays} rays) of the same {w}x{h} frame"
+    else:
+        # calibrate on a sparse sample, then size the real one
+        step0 = max(1, h // 32)
+        t = time.perf_counter()
+        o.render(sc, w, h, depth, rows=(step0 // 2, h, step0), want_ids=False)
+        dt0 = time.perf_counter() - t
+        rows0 = len(range(step0 // 2, h, step0))
+        want_rows = int(min(h, max(8, per_run / (dt0 / rows0))))
+        step = max(1, h // want_rows)
+        sel = (step // 2, h, step)
+        def run():
+            t = time.perf_counter()
+            _, _, n = o.render(sc, w, h, depth, rows=sel, want_ids=False)
+            return n, time.perf_counter() - t
+        run()                                      # warm-up
+        runs = [run() for _ in range(3)]
+        rays = runs[0][0]
+        times = sorted(dt for _, dt in runs)
+        what = (f"every {step}th row ({len(range(*sel))} of {h} rows, {rays} rays) of the same "
+                f"{w}x{h} frame")
+    dt = times[1]
     return {
-        "value": n / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"every {step}th row ({rows} of {h} rows, {n} rays, {dt:.1f} s) of the same "
-                  f"{w}x{h} frame; oracle/rt_oracle.c, gcc -O2 -fopenmp -ffp-contract=off",
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "cpu_model": cpu_model(),
+        "runs_s": [round(x, 3) for x in times], "protocol": "1 warm-up + 3 timed runs, median",
+        "sample": f"{what}; {build}; median {dt:.2f} s",
     }
 
 
@@ -115,11 +140,13 @@ def main():
     ap.add_argument("--screen", choices=["auto", "off", "beam", "bvh"], default="auto",
                     help="work avoidance mode (rt_set_screen); off = plain every-ray-"
                          "every-sphere loop")
-    ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="frames rendered concurrently, each on its own stream with its own "
-                         "resident scene copy (1 = strictly one frame at a time).  Default: 1 on "
-                         "one GPU (a whole frame fills the chip: 5.63 ms against 5.83 with four), "
-                         "4 with --gpus N > 1 (a rank's share of a frame does not)")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="frames rendered concurrently for `value`, each on its own stream with "
+                         "its own resident scene copy (default 1 = strictly one frame at a time, "
+                         "for every N; with --gpus N > 1 a second leg with four in flight is "
+                         "measured as well and reported beside `value`)")
+    ap.add_argument("--no-in-flight-leg", action="store_true",
+                    help="--gpus N > 1: skip the second leg with four frames in flight")
     ap.add_argument("--one-launch", type=int, default=1, choices=[0, 1],
                     help="bounce levels in one launch (default) or a launch per stage and level")
     ap.add_argument("--side-stream", type=int, default=None, choices=[0, 1],
@@ -156,96 +183,108 @@ def main():
     plan = BandPlan(h, w, band_rows, rank, world)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     rtamd.set_screen(args.screen)   # the mode scenes created below start with
-    # Frames in flight: the bounce levels of a frame are one launch whose waves work
-    # through chains of up to max_depth dependent levels, so one frame alone cannot
-    # keep the chip busy once its share of the rays is small (N > 1).  Each slot has
-    # its own resident copy of the scene (its queues and stacks), its own stream and
-    # frame buffer; frame k+1 renders while frame k drains and while its bands travel
-    # to rank 0.  A whole frame on one GPU fills the chip by itself.
-    if args.frames_in_flight is None:
-        args.frames_in_flight = 1 if world == 1 else 4
+    # `value` is measured with ONE frame in flight whatever N is: with N > 1 that is
+    # the strong scaling of a frame, which is what "scaling": "strong" says.  The
+    # bounce levels of a frame are one launch whose waves work through chains of up
+    # to max_depth dependent levels, so a rank's share of a frame cannot keep the
+    # chip busy by itself; a renderer of image sequences hides that by keeping
+    # several frames in flight (each on its own stream, with its own resident scene
+    # copy and frame buffer), and with N > 1 a second leg measures that too and
+    # reports it beside `value` ("frames_in_flight_4"), never instead of it.
     n_buf = max(1, args.frames_in_flight)
-    # several frames in flight: one stream per frame, no side streams inside a
-    # frame (the device has 4 hardware queues; streams sharing one serialise)
-    side = args.side_stream if args.side_stream is not None else (1 if n_buf == 1 else 0)
 
     class Slot:
         pass
-    slots = []
-    for _ in range(n_buf):
-        sl = Slot()
-        sl.scene = rtamd.DeviceScene(sc)
-        sl.scene.set_side_stream(side)
-        sl.scene.set_one_launch(args.one_launch)
-        sl.stream = torch.cuda.Stream(device=dev)
-        sl.fb = plan.alloc_frame(dev)
-        sl.send, sl.recv = plan.alloc_gather(comm_dev)
-        sl.pending = None
-        slots.append(sl)
-    ds = slots[0].scene
-    events = []     # (start, end) pairs around the device work of each timed frame
 
-    def finish(sl):
-        """Wait for the slot's gather and, on rank 0, put the other ranks' bands
-        in place.  The frame is then complete on GPU 0."""
-        if sl.pending is not None:
-            sl.pending.wait()
+    def make_slots(n, side):
+        out = []
+        for _ in range(n):
+            sl = Slot()
+            sl.scene = rtamd.DeviceScene(sc)
+            sl.scene.set_side_stream(side)
+            sl.scene.set_one_launch(args.one_launch)
+            sl.stream = torch.cuda.Stream(device=dev)
+            sl.fb = plan.alloc_frame(dev)
+            sl.send, sl.recv = plan.alloc_gather(comm_dev)
             sl.pending = None
-            plan.scatter_received(sl.fb, sl.recv)
+            out.append(sl)
+        return out
 
-    def step(timed, k=0):
-        sl = slots[k % n_buf]
-        with torch.cuda.stream(sl.stream):
-            finish(sl)
-            if timed:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            sl.scene.render_device(sl.fb.data_ptr(), None, w, h, max_depth=depth,
-                                   band_rows=band_rows, band_index=rank, band_count=world,
-                                   stream=sl.stream.cuda_stream, dev_ray_count=cnt.data_ptr())
-            if timed:
-                e1.record()
-                events.append((e0, e1))
-            sl.pending = plan.gather_to_rank0(sl.fb, sl.send, sl.recv, async_op=True)
+    def timed_leg(slots):
+        """W warm-up frames, then K timed frames between barriers; returns wall
+        seconds (max over ranks), rays of all ranks, this rank's rays per frame and
+        the mean first-to-last-launch device time of a frame."""
+        n = len(slots)
+        events = []
 
-    def drain():
-        for sl in slots:
+        def finish(sl):
+            # wait for the slot's gather and, on rank 0, put the other ranks' bands
+            # in place: the frame is then complete on GPU 0
+            if sl.pending is not None:
+                sl.pending.wait()
+                sl.pending = None
+                plan.scatter_received(sl.fb, sl.recv)
+
+        def step(timed, k=0):
+            sl = slots[k % n]
             with torch.cuda.stream(sl.stream):
                 finish(sl)
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                sl.scene.render_device(sl.fb.data_ptr(), None, w, h, max_depth=depth,
+                                       band_rows=band_rows, band_index=rank, band_count=world,
+                                       stream=sl.stream.cuda_stream, dev_ray_count=cnt.data_ptr())
+                if timed:
+                    e1.record()
+                    events.append((e0, e1))
+                sl.pending = plan.gather_to_rank0(sl.fb, sl.send, sl.recv, async_op=True)
 
-    for k in range(max(args.warmup, n_buf)):
-        step(False, k)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    cnt.zero_()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(True, k)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # device time of one frame's launches, first to last; with several frames in
-    # flight these intervals overlap, so this is a frame's latency, not 1/throughput
-    frame_latency_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+        def drain():
+            for sl in slots:
+                with torch.cuda.stream(sl.stream):
+                    finish(sl)
 
-    for sl in slots:
-        if sl.scene.queue_overflowed():
-            raise SystemExit("bounce-ray queue overflowed: the frames are incomplete, no number reported")
-    rays = cnt.clone()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_rays = int(rays.item())
-    dt = float(tmax.item())
-    my_rays_per_frame = int(cnt.item()) / args.steps
+        for k in range(max(args.warmup, n)):
+            step(False, k)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        cnt.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(True, k)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for sl in slots:
+            if sl.scene.queue_overflowed():
+                raise SystemExit("bounce-ray queue overflowed: the frames are incomplete, "
+                                 "no number reported")
+        rays = cnt.clone()
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # with several frames in flight the first-to-last-launch intervals overlap:
+        # a frame's latency, not 1/throughput
+        return {"dt": float(tmax.item()), "total_rays": int(rays.item()),
+                "my_rays_per_frame": int(cnt.item()) / args.steps,
+                "frame_latency_ms": float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))}
+
+    # several frames in flight: one stream per frame, no side streams inside a
+    # frame (the device has 4 hardware queues; streams sharing one serialise)
+    side = args.side_stream if args.side_stream is not None else (1 if n_buf == 1 else 0)
+    slots = make_slots(n_buf, side)
+    leg = timed_leg(slots)
+    dt, total_rays = leg["dt"], leg["total_rays"]
+    my_rays_per_frame = leg["my_rays_per_frame"]
 
     # ---- one frame at a time, stage by stage (not part of `value`) ----
     # HIP events recorded by the library on the frame's own stream around the
@@ -268,6 +307,19 @@ def main():
     stage_ms = staged_frames(min(10, max(2, args.steps)))
     one_frame_ms = float(sum(stage_ms))
 
+    # ---- N > 1: the same split with four frames in flight, beside `value` ----
+    in_flight = None
+    if world > 1 and n_buf == 1 and not args.no_in_flight_leg:
+        more = make_slots(4, 0)
+        leg4 = timed_leg(more)
+        in_flight = {"frames_in_flight": 4, "ms_per_frame": leg4["dt"] / args.steps * 1e3,
+                     "mrays_per_s": leg4["total_rays"] / leg4["dt"] / 1e6,
+                     "frame_latency_ms": leg4["frame_latency_ms"],
+                     "note": "throughput of a sequence of frames, four in flight per rank; "
+                             "not the strong scaling of one frame, which is `value`"}
+        for sl in more:
+            sl.scene.close()
+
     if rank == 0:
         value = total_rays / dt / 1e6
         out = {
@@ -283,11 +335,14 @@ def main():
                        "sharding": f"row bands of {band_rows}, round-robin over {world} GPU(s)",
                        "screen": args.screen, "frames_in_flight": n_buf,
                        "one_launch": args.one_launch},
-            "frame_latency_ms": frame_latency_ms,
-            # the same frame with nothing else on the GPU: sum of the three stages
+            "frame_latency_ms": leg["frame_latency_ms"],
+            # this rank's share of the frame with nothing else on its GPU and no
+            # gather: sum of the three stages
             "one_frame_ms": one_frame_ms,
             "one_frame_mrays_per_s": my_rays_per_frame / (one_frame_ms * 1e-3) / 1e6,
         }
+        if in_flight is not None:
+            out["frames_in_flight_4"] = in_flight
         out["roofline"] = roofline(name, args, world, stage_ms, my_rays_per_frame, n_tests_per_ray)
         if world == 1 and args.screen != "off" and not args.no_plain_loop:
             if sc.t_size + sc.s_size > PLAIN_LOOP_MAX_PRIMS:
@@ -319,6 +374,20 @@ def main():
         dist.destroy_process_group()
 
 
+def kernel_source_sha():
+    """Hash of the device code's source files: stored beside the profiled counters,
+    so that instruction counts of one build are never combined with stage times of
+    another."""
+    import hashlib
+    hsh = hashlib.sha256()
+    d = os.path.join(REPO, "ray-tracer_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, fn), "rb") as f:
+                hsh.update(fn.encode() + b"\0" + f.read())
+    return hsh.hexdigest()[:16]
+
+
 def profiled_counters(workload):
     """Per-frame instruction and traffic counts of the library's kernels, by
     stage, from rocprofv3 --pmc passes of this same program with one frame in
@@ -341,6 +410,12 @@ def roofline(name, args, world, stage_ms, rays_per_frame, flop_per_ray):
     this path may not fuse, so the ceiling is half the FMA peak.  The fraction
     cannot exceed 1 whatever work the hierarchies avoid."""
     prof = profiled_counters(name) if (world == 1 and args.screen == "auto") else None
+    stale = None
+    if prof is not None and prof.get("source_sha") != kernel_source_sha():
+        # the counters were taken from another build of the kernels: their
+        # instruction counts say nothing about this one's
+        stale = prof.get("source_sha")
+        prof = None
     stages = {}
     for k, st in enumerate(STAGES):
         e = {"ms": stage_ms[k]}
@@ -364,6 +439,8 @@ def roofline(name, args, world, stage_ms, rays_per_frame, flop_per_ray):
     d = stages[dom]
     r = {"bound": "valu_fp32", "kernel": dom, "kernel_ms": d["ms"],
          "achieved": d.get("tlaneops_per_s"), "peak": PEAK_UNFUSED_TLANEOPS, "unit": "TFLOP/s",
+         "achieved_counts": "executed vector lane-operations (moves, integer and compare "
+                            "instructions included): an upper bound on the flop rate",
          "frac": d.get("frac"), "traffic": d.get("hbm_bytes"),
          "stages": stages,
          "note": "achieved = vector lane-operations executed per second by the longest stage "
@@ -375,7 +452,11 @@ def roofline(name, args, world, stage_ms, rays_per_frame, flop_per_ray):
     if d.get("hbm_bytes") is not None:
         r["hbm"] = {"achieved": d["hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": d["hbm_gbs"] / PEAK_HBM_GBS}
-    if prof is None:
+    if stale is not None:
+        r["note"] += (f"; profiles/counters.json was taken from another build of the kernels "
+                      f"(source hash {stale}, this tree {kernel_source_sha()}): achieved is null "
+                      f"until tools/profile.sh is run again")
+    elif prof is None:
         r["note"] += "; no counter passes committed for this workload/mode: achieved is null"
     return r
 

@@ -120,6 +120,29 @@ void rt_cache_clear(void);
 /* How many scenes those entry points have built so far in this process
  * (diagnostic: lets a host or a test see that a call reused the kept scene).  */
 uint64_t rt_cache_builds(void);
+/* The content hashes above (64-bit, not cryptographic: they notice arrays that
+ * were edited in place between calls, they do not resist an adversary) cost a
+ * pass over every array per call: 36 MB for a million triangles.  A host that
+ * never edits a scene's arrays in place (the reference's main.cpp builds them
+ * once, main.cpp:98-101, and only reads them afterwards) may say so: with
+ * on != 0 the same pointers and sizes ARE the same scene and nothing is hashed.
+ * Process-wide; no counterpart in the reference.                              */
+void rt_cache_trust_pointers(int on);
+
+/* The one-call entry points end with a device-to-host copy of the frame into
+ * `rgb` (and `hit_ids`).  Into ordinary pageable memory (new[], malloc: what the
+ * reference allocates at main.cpp:91) that copy goes through the runtime's
+ * staging buffers, 1.9 ms for a 3840 x 2160 frame, twice the render of a depth-1
+ * frame; into page-locked memory it runs at the rate of the PCIe link, 0.6 ms.
+ * rt_alloc_host_buffer returns such memory (hipHostMalloc) for a host that is
+ * willing to allocate its frame buffer through the library, one line changed in
+ * the reference's main.cpp; rt_free_host_buffer releases it.  (Pinning a buffer the
+ * host already has, hipHostRegister, is refused by the driver stack this library
+ * was developed on, so no entry point offers it.)  Either kind of buffer is
+ * accepted everywhere; nothing else changes.  No counterpart in the reference,
+ * whose frame buffer is written by host threads.                               */
+int rt_alloc_host_buffer(size_t bytes, void **out);
+void rt_free_host_buffer(void *p);
 
 /* ---- resident scene + device-side rendering -------------------------------
  * The `map(to: ...)` clause of renderer.cpp:13-21 as an explicit object: the
@@ -159,9 +182,14 @@ int rt_render_device(rt_scene *scene, const camera *cam, const rt_frame *frame,
 /* Bounce rays wait in a queue in HBM sized at 4 rays per pixel of the call (see
  * rt_scene_set_rays_per_pixel).  If a frame spawns more, the excess is dropped
  * and this reports 1 after the frame (blocking read): the image is incomplete.
- * gpu_render / gpu_render_ids check it themselves, enlarge the queue and render
- * again; they return RT_ERR_CAPACITY only if the largest queue overflows too,
- * which the weight cut-off makes impossible.                                  */
+ * gpu_render / gpu_render_ids check it themselves and render again: first with
+ * a launch per bounce level instead of one launch for all (rt_scene_set_one_launch
+ * 0: the one-launch form keeps a stack per resident wave, which can overflow
+ * whatever the queue setting and whose size grows with it five thousand-fold),
+ * then with eight times the queue capacity per attempt; they return
+ * RT_ERR_CAPACITY only if the largest queue overflows too, which the weight
+ * cut-off makes impossible.  A caller of rt_render_device has the same two
+ * remedies: rt_scene_set_one_launch(scene, 0) and rt_scene_set_rays_per_pixel. */
 int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
 
 /* Capacity of the bounce-ray queues of later rt_render_device calls: n rays per
@@ -172,6 +200,17 @@ int rt_scene_queue_overflowed(rt_scene *scene, int *overflowed);
  * gpu_render / gpu_render_ids do exactly that by themselves (x8 per attempt).
  * No counterpart in the reference.                                            */
 int rt_scene_set_rays_per_pixel(rt_scene *scene, int n);
+
+/* Upper limit, in bytes, of the device memory a scene may take for the bounce
+ * machinery of its frames (ray queues, per-wave stacks, per-pixel sums; it grows
+ * with the frame size, max_depth, the number of lights and the rays-per-pixel
+ * setting).  0 = no limit (default).  A frame that would need more fails with
+ * RT_ERR_CAPACITY before anything is allocated, exactly as when the device is
+ * out of memory; in both cases the scene is left without any machinery and the
+ * next frame starts afresh.  gpu_render* react to RT_ERR_CAPACITY by rendering
+ * the frame with a launch per bounce level, whose needs are smaller, before they
+ * give up.  No counterpart in the reference.                                  */
+int rt_scene_set_arena_limit(rt_scene *scene, uint64_t max_bytes);
 
 /* ---- work avoidance (no counterpart in the reference) ----------------------
  * The reference tests every ray against every primitive (renderer.cpp:156-177).
@@ -271,10 +310,22 @@ int gpu_check_intersection(rt_scene *scene, int64_t n, const float *orig,
                            const float *dir, int32_t *kind, int32_t *index,
                            float *P);
 
+/* The specular term of renderer.cpp:106-110 on n caller-supplied values (host
+ * arrays): strength[i] = (float)pow((double)lang[i], 20.0) as the device's
+ * shading computes it (five double multiplies instead of libm's pow) and
+ * specular[i] = (unsigned char)(color[i] * strength[i]).  For known-answer tests
+ * of that one substitution; rendering does not go through this entry point.   */
+int gpu_specular_terms(int64_t n, const float *lang, const uint8_t *color,
+                       float *strength, uint8_t *specular);
+
 /* check_intersection as the reference's own callers use it (renderer.hpp:21-23:
  * the scene arrays and ONE ray per call): the scene is kept resident exactly as
  * gpu_render keeps it, so only the first call for a set of arrays uploads and
- * builds.  Colours play no part: scene->color_tri / color_sphere may be NULL.
+ * builds; a scene that gpu_render (or the shim's render()) left resident serves
+ * these calls as it is when the triangles, spheres and radii are the same, so a
+ * host that alternates render() and check_intersection() builds once.  Only the
+ * geometry is hashed per call (nothing with rt_cache_trust_pointers).
+ * Colours play no part: scene->color_tri / color_sphere may be NULL.
  * kind, index, P: one element (three floats for P), semantics as above.      */
 int gpu_check_intersection_arrays(const scene_desc *scene, const float *orig,
                                   const float *dir, int32_t *kind,

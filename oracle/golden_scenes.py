@@ -45,6 +45,51 @@ def full_frame_scenes():
     }
 
 
+def specular_inputs():
+    """(lang, colour) pairs for the specular term of renderer.cpp:106-110:
+    specular = (unsigned char)(colour * pow(lang, 20)).  For every colour c and
+    every integer k <= c the float nearest to (k/c)^(1/20) and its three
+    neighbours on either side (there colour * pow sits within a few ulp of the
+    integer k, where a last-place difference in pow would change the byte), then
+    values on a regular grid, the ends of the range, and seeded random values
+    with random colours."""
+    lang, col = [], []
+    for c in range(1, 256):
+        k = np.arange(1, c + 1, dtype=np.float64)
+        centre = ((k / c) ** (1.0 / 20.0)).astype(np.float32)
+        bits = centre.view(np.int32)
+        for d in range(-3, 4):
+            v = (bits + d).view(np.float32)
+            lang.append(v)
+            col.append(np.full(len(v), c, np.uint8))
+    grid = np.linspace(0.0, 1.0, 4097, dtype=np.float32)
+    lang.append(grid)
+    col.append(np.full(len(grid), 255, np.uint8))
+    ends = np.array([0.0, 1e-30, 1e-10, 0.5, 0.999999, 1.0, 1.0000001, 1.0000002], np.float32)
+    lang.append(ends)
+    col.append(np.full(len(ends), 200, np.uint8))
+    rng = np.random.RandomState(20)
+    r = rng.uniform(0.6, 1.0, 60000).astype(np.float32)   # below 0.6 every byte is 0
+    lang.append(r)
+    col.append(rng.randint(1, 256, len(r)).astype(np.uint8))
+    return np.concatenate(lang).astype(np.float32), np.concatenate(col).astype(np.uint8)
+
+
+def highlight_scene():
+    """A frame whose image is mostly specular highlight: a few large spheres and
+    the wall, every channel of every colour different, three lights close to the
+    line of sight so that lang (renderer.cpp:104) is near 1 over wide areas and
+    the byte (unsigned char)(colour * pow(lang, 20)) takes every value."""
+    c = np.array([[0, 0, -30], [-16, 6, -34], [15, -5, -26], [6, 9, -22], [-7, -8, -20]],
+                 np.float32)
+    r = np.array([9, 7, 6, 4, 3.5], np.float32)
+    col = np.array([[251, 193, 127], [89, 241, 167], [173, 101, 255], [233, 233, 61],
+                    [47, 149, 211]], np.uint8)
+    tcol = np.array([[255, 125, 125], [199, 251, 83]], np.uint8)
+    lights = np.array([[0.5, 1.0, 1.5], [-3, -1, 2], [2, 4, 0]], np.float32)
+    return rtamd.Scene(rtamd.WALL_TRIS.copy(), tcol, c, r, col, lights)
+
+
 def random_rays(n, seed):
     rng = np.random.RandomState(seed)
     o = np.stack([rng.uniform(-10, 10, n), rng.uniform(-6, 6, n), rng.uniform(-30, 3, n)],

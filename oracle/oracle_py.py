@@ -161,9 +161,23 @@ class Oracle:
             self.L.oracle_reflect(d[i].ctypes.data, n[i].ctypes.data, out[i].ctypes.data)
         return out
 
+    def specular(self, lang, color):
+        return _specular(self.L, "oracle_specular_batch", lang, color)
+
     def length(self, v):
         return np.array([self.L.oracle_length(v[i].ctypes.data) for i in range(len(v))],
                         np.float32)
+
+
+def _specular(L, fn, lang, color):
+    lang = np.ascontiguousarray(lang, np.float32).reshape(-1)
+    color = np.ascontiguousarray(color, np.uint8).reshape(-1)
+    strength = np.empty(len(lang), np.float32)
+    spec = np.empty(len(lang), np.uint8)
+    getattr(L, fn)(C.c_long(len(lang)), C.c_void_p(lang.ctypes.data),
+                   C.c_void_p(color.ctypes.data), C.c_void_p(strength.ctypes.data),
+                   C.c_void_p(spec.ctypes.data))
+    return strength, spec
 
 
 class Ref:
@@ -250,6 +264,10 @@ class Ref:
         self.L.ref_reflect_batch(C.c_long(len(d)), C.c_void_p(d.ctypes.data),
                                  C.c_void_p(n.ctypes.data), C.c_void_p(out.ctypes.data))
         return out
+
+    def specular(self, lang, color):
+        """renderer.cpp:106-110 compiled beside the reference (ref_harness.cpp)."""
+        return _specular(self.L, "ref_specular_batch", lang, color)
 
     def length(self, v):
         out = np.zeros(len(v), np.float32)

@@ -11,6 +11,7 @@
 #include "renderer.hpp" // reference header: render, check_intersection, CANVAS_*
 #include "maths.hpp"    // reference header: vector helpers and the two ray tests
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -111,6 +112,21 @@ void ref_reflect_batch(long n, float *dir, float *nrm, float *out) {
 void ref_length_batch(long n, float *v, float *out) {
   for (long i = 0; i < n; i++)
     out[i] = length(v + 3 * i);
+}
+
+// The specular term of renderer.cpp:106-110.  The reference has no function for
+// it (the statements sit inside render()'s light loop), so the two statements are
+// restated here, and what these vectors pin is the value the reference's build
+// gets from its C library for pow(double, 20.0) at the given arguments, followed
+// by the reference's conversions: compiled by the same compiler with the same
+// flags and linked against the same libm as renderer.cpp beside it.
+void ref_specular_batch(long n, float *lang, unsigned char *color,
+                        float *strength, unsigned char *specular) {
+  for (long i = 0; i < n; i++) {
+    float specular_strength = pow(lang[i], 20); // renderer.cpp:106 (float, int)
+    strength[i] = specular_strength;
+    specular[i] = color[i] * specular_strength; // renderer.cpp:108-110
+  }
 }
 
 // The reference's grid generator (main.cpp:358-395).  Caller provides arrays of

@@ -261,6 +261,17 @@ static void hit_normal_color(const scene_desc *sc, hit_info *hi) {
   oracle_normalize(hi->n); /* renderer.cpp:76 */
 }
 
+/* The specular term on its own, renderer.cpp:106-110 (known-answer door; the
+ * same two statements as in phong_light below). */
+void oracle_specular_batch(long n, const float *lang, const uint8_t *color,
+                           float *strength, uint8_t *specular) {
+  for (long i = 0; i < n; i++) {
+    float s = (float)pow((double)lang[i], 20.0); /* renderer.cpp:106 */
+    strength[i] = s;
+    specular[i] = (uint8_t)(color[i] * s);       /* :108-110 */
+  }
+}
+
 /* One light's Phong term, renderer.cpp:85-115.  Returns angle, fills fColor
  * and the unit direction to the light. */
 static float phong_light(const hit_info *hi, const float dir[3],

@@ -32,6 +32,8 @@ int oracle_check_intersection(const float *tris, int t_size,
 void oracle_check_intersection_batch(const scene_desc *sc, long n,
                                      const float *orig, const float *dir,
                                      int32_t *kind, int32_t *index, float *P);
+void oracle_specular_batch(long n, const float *lang, const uint8_t *color,
+                           float *strength, uint8_t *specular);
 void oracle_primary_ray(const camera *cam, int w, int h, int i, int j,
                         float orig[3], float dir[3]);
 uint64_t oracle_render(const scene_desc *sc, const camera *cam, uint8_t *fb,

@@ -78,6 +78,7 @@ constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
 // (pixel << 6 | depth, rt_kernels.hip queue_push).
 constexpr size_t kMaxBouncePixels = (size_t)1 << 26;
 constexpr size_t kSmallSharePixels = 1500000; // see bounce_needs
+constexpr size_t kCheckPinnedRays = 256;      // see gpu_check_intersection
 
 // What the bounce levels of one frame need besides the scene: ray queues, hit
 // lists, shadow items, control words and the per-pixel integer sums.  All of it
@@ -218,6 +219,7 @@ struct rt_scene {
   // bounce machinery, allocated on the first frame with bounces
   DevBuf<unsigned char> arena_mem;
   BounceArena arena;
+  size_t arena_limit = 0; // rt_scene_set_arena_limit: 0 = none
   // queue capacity per level: this many rays per owned pixel (+ 65536).  No level
   // can hold more than 256 per pixel: every queued ray weighs >= 2^-8 and the
   // weights of one pixel's rays at one level sum to at most 1.
@@ -228,9 +230,11 @@ struct rt_scene {
   bool timing = false;
   hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
   int timed_stages = 0;
-  // staging for gpu_check_intersection (grow-only)
+  // staging for gpu_check_intersection (grow-only); for a few rays a block of
+  // pinned host memory that the kernel reads and writes directly
   DevBuf<float> chk_in, chk_P;
   DevBuf<int32_t> chk_out;
+  float *chk_pin = nullptr, *chk_pin_dev = nullptr;
 
   ~rt_scene() {
     for (hipEvent_t e : {ev_eye, ev_frame, ev_fork[0], ev_fork[1], ev_join[0], ev_join[1], ev_t[0],
@@ -239,6 +243,8 @@ struct rt_scene {
         (void)hipEventDestroy(e);
     if (side)
       (void)hipStreamDestroy(side);
+    if (chk_pin)
+      (void)hipHostFree(chk_pin);
   }
 
   rt::SceneDev dev() const {
@@ -525,7 +531,11 @@ BounceNeeds bounce_needs(const rt_scene *S, int max_depth, size_t frame_pixels,
   return n;
 }
 
-// The scene's own arena: grown (never shrunk) to what the frame needs.
+// The scene's own arena: grown (never shrunk) to what the frame needs.  The old
+// region is given back before the new one is asked for (both side by side may not
+// fit), and the scene forgets it first: when the allocation fails the scene has no
+// arena at all, and the next frame, perhaps a smaller one, starts from nothing
+// instead of carving freed memory.
 int ensure_arena(rt_scene *S, const BounceNeeds &need) {
   if (!S->arena.counts || !S->arena.have.covers(need)) {
     BounceNeeds n = S->arena.have;
@@ -533,11 +543,26 @@ int ensure_arena(rt_scene *S, const BounceNeeds &need) {
     BounceArena probe;
     const size_t bytes = probe.carve(nullptr, n);
     HIP_TRY(hipDeviceSynchronize()); // nothing may still use the old region
-    HIP_TRY(S->arena_mem.alloc(bytes));
     S->arena = BounceArena();
-    S->arena.carve(S->arena_mem.p, n);
+    S->arena_mem.release();
+    if (S->arena_limit && bytes > S->arena_limit)
+      return fail(RT_ERR_CAPACITY,
+                  "the frame's bounce machinery needs %zu bytes, the scene's limit is %zu "
+                  "(rt_scene_set_arena_limit)",
+                  bytes, S->arena_limit);
+    const hipError_t e = S->arena_mem.alloc(bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError(); // the failure is reported here, not by a later launch
+      S->arena_mem.release();
+      return fail(e == hipErrorOutOfMemory ? RT_ERR_CAPACITY : RT_ERR_HIP,
+                  "hipMalloc of %zu bytes for the bounce machinery failed: %s", bytes,
+                  hipGetErrorString(e));
+    }
+    BounceArena fresh;
+    fresh.carve(S->arena_mem.p, n);
     // the per-pixel sums start at zero and k_compose leaves them at zero
-    HIP_TRY(hipMemset(S->arena.extra, 0, n.frame_pixels * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(fresh.extra, 0, n.frame_pixels * sizeof(unsigned long long)));
+    S->arena = fresh;
   }
   if (!S->side) {
     HIP_TRY(hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
@@ -681,6 +706,14 @@ static int render_frame(rt_scene *S, const BounceArena *A, hipStream_t side, con
   const int rc = render_frame_launches(S, A, side, cam, fr, P,
                                        dev_ray_count ? S->ray_parts.p : nullptr, dev_verify,
                                        dev_ray_count, &summed);
+  if (rc != RT_OK && dev_ray_count) {
+    // a frame that stopped half way (a launch failed) leaves what its first kernels
+    // counted in the partial counters: they must be zero when the next frame starts
+    (void)hipMemsetAsync(S->ray_parts.p, 0,
+                         (size_t)rt::RAY_PARTS * rt::RAY_PART_STRIDE * sizeof(uint64_t),
+                         (hipStream_t)fr->stream);
+    (void)hipGetLastError();
+  }
   if (rc != RT_OK || !dev_ray_count || summed)
     return rc;
   HIP_TRY(rt::launch_sum_rays(S->ray_parts.p, dev_ray_count, (hipStream_t)fr->stream));
@@ -1029,6 +1062,13 @@ int rt_scene_set_rays_per_pixel(rt_scene *S, int n) {
   return RT_OK;
 }
 
+int rt_scene_set_arena_limit(rt_scene *S, uint64_t max_bytes) {
+  if (!S)
+    return fail(RT_ERR_BAD_ARG, "scene is NULL");
+  S->arena_limit = (size_t)max_bytes;
+  return RT_OK;
+}
+
 int rt_scene_set_screen(rt_scene *S, int mode) {
   if (!S)
     return fail(RT_ERR_BAD_ARG, "scene is NULL");
@@ -1246,21 +1286,34 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
 // ---- scenes kept between one-call renders -------------------------------------
 // gpu_render* receive host arrays every time.  The device copy of the last scene
 // (per device) is kept and reused when the next call brings the same pointers,
-// sizes and bytes; a 64-bit hash of all arrays decides the last point (a
-// million triangles hash in a few ms, their hierarchy takes 0.3 s to build).
+// sizes and bytes; two 64-bit hashes, one of the geometry and one of everything
+// else, decide the last point (a million triangles hash in a few ms, their
+// hierarchy takes 0.3 s to build).  The hashes are not cryptographic: they catch
+// arrays edited in place between calls, not an adversary.  A host that never
+// edits its arrays in place can switch the hashing off (rt_cache_trust_pointers).
 } // extern "C"
 
 namespace {
 
 constexpr int kMaxCachedDevices = 16;
+constexpr int kFrameChunks = 4; // render_cached: row chunks whose copies back overlap the render
 
 struct SceneKey {
   scene_desc d;
-  uint64_t hash = 0;
+  uint64_t geo_hash = 0;  // tris, spheres, radius
+  uint64_t rest_hash = 0; // colours, lights, materials
   bool operator==(const SceneKey &o) const {
-    return memcmp(&d, &o.d, sizeof d) == 0 && hash == o.hash;
+    return memcmp(&d, &o.d, sizeof d) == 0 && geo_hash == o.geo_hash && rest_hash == o.rest_hash;
+  }
+  // the same primitives, whatever their colours, lights and materials: all that
+  // check_intersection (renderer.hpp:21-23) looks at
+  bool same_geometry(const SceneKey &o) const {
+    return d.tris == o.d.tris && d.t_size == o.d.t_size && d.spheres == o.d.spheres &&
+           d.radius == o.d.radius && d.s_size == o.d.s_size && geo_hash == o.geo_hash;
   }
 };
+
+std::atomic<int> g_trust_pointers{0}; // rt_cache_trust_pointers
 
 uint64_t hash_bytes(uint64_t h, const void *p, size_t n) {
   // four interleaved multiply-xor lanes over 8-byte words, then the tail
@@ -1280,7 +1333,9 @@ uint64_t hash_bytes(uint64_t h, const void *p, size_t n) {
   return r ^ (uint64_t)n;
 }
 
-SceneKey scene_key(const scene_desc *s) {
+// geometry_only: the caller is check_intersection; nothing but the geometry is
+// looked at, so nothing else is hashed (one ray per call must stay cheap).
+SceneKey scene_key(const scene_desc *s, bool geometry_only = false) {
   SceneKey k;
   memset(&k.d, 0, sizeof k.d); // padding bytes compare equal
   k.d.tris = s->tris;
@@ -1294,12 +1349,18 @@ SceneKey scene_key(const scene_desc *s) {
   k.d.l_size = s->l_size;
   k.d.mat_tri = s->mat_tri;
   k.d.mat_sphere = s->mat_sphere;
+  if (g_trust_pointers.load())
+    return k;
   uint64_t h = 0x6a09e667f3bcc908ull;
   h = hash_bytes(h, s->tris, sizeof(float) * 9 * (size_t)s->t_size);
-  if (s->color_tri)
-    h = hash_bytes(h, s->color_tri, 3 * (size_t)s->t_size);
   h = hash_bytes(h, s->spheres, sizeof(float) * 3 * (size_t)s->s_size);
   h = hash_bytes(h, s->radius, sizeof(float) * (size_t)s->s_size);
+  k.geo_hash = h;
+  if (geometry_only)
+    return k;
+  h = 0xbb67ae8584caa73bull;
+  if (s->color_tri)
+    h = hash_bytes(h, s->color_tri, 3 * (size_t)s->t_size);
   if (s->color_sphere)
     h = hash_bytes(h, s->color_sphere, 3 * (size_t)s->s_size);
   h = hash_bytes(h, s->lights, sizeof(float) * 3 * (size_t)s->l_size);
@@ -1307,54 +1368,87 @@ SceneKey scene_key(const scene_desc *s) {
     h = hash_bytes(h, s->mat_tri, sizeof(rt_material) * (size_t)s->t_size);
   if (s->mat_sphere)
     h = hash_bytes(h, s->mat_sphere, sizeof(rt_material) * (size_t)s->s_size);
-  k.hash = h;
+  k.rest_hash = h;
   return k;
 }
 
+// One kept scene.  Slot d belongs to device d for the one-device entry points;
+// gpu_render_multi uses slots 0 .. n_devices-1 (which are devices 0 .. n_devices-1
+// unless several slots are mapped onto one device for a rehearsal, see there).
 struct CachedScene {
+  std::mutex mutex;       // held by the call that renders from this slot
   rt_scene *scene = nullptr;
+  int device = -1;        // the device the scene and the buffers below live on
   SceneKey key;
   // frame buffers of the one-call entry points, grow-only
   DevBuf<uint8_t> fb;
   DevBuf<int32_t> ids;
   DevBuf<uint64_t> cnt;
-  hipStream_t stream = nullptr; // gpu_render_multi: this device's stream
-};
-std::mutex g_cache_mutex;
-CachedScene g_cache[kMaxCachedDevices];
-uint64_t g_cache_builds = 0; // scenes built by cached_scene (for tests)
+  hipStream_t stream = nullptr; // this slot's stream (gpu_render_multi, chunked frames)
+  hipStream_t copy_stream = nullptr;          // chunked frames: the copies back
+  hipEvent_t ev_chunk[kFrameChunks] = {};     // chunk k rendered
 
-// The resident scene for `s` on the current device, built if the kept one is a
-// different scene.  Call with g_cache_mutex held.
-int cached_scene(const scene_desc *s, const SceneKey &key, CachedScene **out,
-                 bool need_colors = true) {
+  // Everything this slot holds, on the device it was made on.
+  void drop() {
+    if (!scene && !fb.p && !ids.p && !cnt.p && !stream && !copy_stream)
+      return;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (device >= 0)
+      (void)hipSetDevice(device);
+    rt_scene_destroy(scene);
+    scene = nullptr;
+    fb.release();
+    ids.release();
+    cnt.release();
+    if (stream)
+      (void)hipStreamDestroy(stream);
+    stream = nullptr;
+    if (copy_stream)
+      (void)hipStreamDestroy(copy_stream);
+    copy_stream = nullptr;
+    for (hipEvent_t &e : ev_chunk) {
+      if (e)
+        (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    device = -1;
+    if (have)
+      (void)hipSetDevice(cur);
+  }
+};
+CachedScene g_cache[kMaxCachedDevices];
+std::atomic<uint64_t> g_cache_builds{0}; // scenes built by cached_scene (for tests)
+
+// The resident scene for `s` in slot C on the current device, built if the kept
+// one is a different scene.  Call with C.mutex held.  need_colors false: the
+// caller is check_intersection, which any kept scene of the same geometry serves.
+int cached_scene(CachedScene &C, const scene_desc *s, const SceneKey &key, bool need_colors = true) {
   int rc;
   if ((rc = check_scene_desc(s, need_colors)) || (rc = ensure_device()))
     return rc;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= kMaxCachedDevices)
-    return fail(RT_ERR_UNSUPPORTED, "device %d: only devices 0..%d keep a scene", dev,
-                kMaxCachedDevices - 1);
-  CachedScene &C = g_cache[dev];
   const int mode = g_default_screen.load();
-  if (!C.scene || !(C.key == key)) {
-    rt_scene_destroy(C.scene);
-    C.scene = nullptr;
+  const bool usable = C.scene && C.device == dev &&
+                      (need_colors ? C.key == key : C.key.same_geometry(key));
+  if (!usable) {
+    C.drop(); // the buffers too when the slot moves to another device
+    C.device = dev;
     if ((rc = scene_create(s, need_colors, &C.scene)))
       return rc;
     C.key = key;
     g_cache_builds++;
   }
   C.scene->screen = mode; // the one-call entry points follow rt_set_screen
-  *out = &C;
   return RT_OK;
 }
 
 // One frame on the current device from the kept scene into the kept buffers
 // (launches only; the caller synchronises).
 int cached_frame(CachedScene &C, const camera *cam, bool want_ids, int w, int h, int max_depth,
-                 int flags, int band_rows, int band_index, int band_count, hipStream_t st) {
+                 int flags, int band_rows, int band_index, int band_count, hipStream_t st,
+                 bool reset_count = true) {
   const size_t npx = (size_t)w * h;
   if (C.fb.n < npx * 4)
     HIP_TRY(C.fb.alloc(npx * 4));
@@ -1362,7 +1456,8 @@ int cached_frame(CachedScene &C, const camera *cam, bool want_ids, int w, int h,
     HIP_TRY(C.ids.alloc(npx));
   if (!C.cnt.p)
     HIP_TRY(C.cnt.alloc(1));
-  HIP_TRY(hipMemsetAsync(C.cnt.p, 0, sizeof(uint64_t), st));
+  if (reset_count)
+    HIP_TRY(hipMemsetAsync(C.cnt.p, 0, sizeof(uint64_t), st));
   rt_frame fr;
   memset(&fr, 0, sizeof fr);
   fr.dev_fb = C.fb.p;
@@ -1378,6 +1473,23 @@ int cached_frame(CachedScene &C, const camera *cam, bool want_ids, int w, int h,
   return rt_render_device(C.scene, cam, &fr, C.cnt.p);
 }
 
+// A frame of a one-call entry point dropped bounce rays, or its bounce machinery
+// could not be allocated: what to change before rendering it again.  The
+// one-launch path keeps a stack per resident wave, which grows with the queue
+// setting times five thousand waves; the launch-per-level path has frame-wide
+// queues only, and at 256 rays per pixel they cannot overflow.  So: leave the
+// one-launch path first, then enlarge the queues.  False: nothing left to try.
+bool next_attempt(rt_scene *S) {
+  if (uses_trace(S)) {
+    S->one_launch = 0;
+    return true;
+  }
+  if (S->rays_per_pixel >= 256)
+    return false;
+  S->rays_per_pixel = S->rays_per_pixel * 8 > 256 ? 256 : S->rays_per_pixel * 8;
+  return true;
+}
+
 int render_cached(const scene_desc *scene, const camera *cam, uint8_t *rgb, int32_t *hit_ids,
                   uint64_t *n_rays, int w, int h, int max_depth, int flags) {
   if (!cam || !rgb)
@@ -1385,19 +1497,68 @@ int render_cached(const scene_desc *scene, const camera *cam, uint8_t *rgb, int3
   if (w <= 0 || h <= 0)
     return fail(RT_ERR_BAD_ARG, "frame size %dx%d", w, h);
   int rc = check_scene_desc(scene);
-  if (rc)
+  if (rc || (rc = ensure_device()))
     return rc;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxCachedDevices)
+    return fail(RT_ERR_UNSUPPORTED, "device %d: only devices 0..%d keep a scene", dev,
+                kMaxCachedDevices - 1);
   const SceneKey key = scene_key(scene);
-  std::lock_guard<std::mutex> lock(g_cache_mutex);
-  CachedScene *C = nullptr;
-  if ((rc = cached_scene(scene, key, &C)))
+  CachedScene &C = g_cache[dev];
+  // one slot, one call at a time; calls on other devices do not wait for this one
+  std::lock_guard<std::mutex> lock(C.mutex);
+  if ((rc = cached_scene(C, scene, key)))
     return rc;
-  rt_scene *S = C->scene;
+  rt_scene *S = C.scene;
   const size_t npx = (size_t)w * h;
-  // render; if a bounce queue overflowed, again with eight times the capacity
-  // (at 256 rays per pixel it cannot overflow)
+  const bool bounces =
+      !(flags & RT_FRAME_UNLIT) && max_depth > 1 && (S->has_mat_tri || S->has_mat_sph);
+  if (!bounces && h >= 16 * kFrameChunks) {
+    // A frame without bounce levels (what render() of the reference asks for) is
+    // finished row by row: it is rendered as kFrameChunks launches over
+    // contiguous blocks of rows, and the copy back of a block runs, on a second
+    // stream, while the next blocks render.  The copy takes longer than the
+    // render (pageable memory: 1.9 ms against 1.0 ms for 3840 x 2160), so the
+    // call then lasts about as long as the copy alone.
+    if (!C.stream)
+      HIP_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+    if (!C.copy_stream)
+      HIP_TRY(hipStreamCreateWithFlags(&C.copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : C.ev_chunk)
+      if (!e)
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const int band_rows = ((h + kFrameChunks - 1) / kFrameChunks + 7) & ~7;
+    const int chunks = (h + band_rows - 1) / band_rows; // <= kFrameChunks; chunk k = band k
+    for (int k = 0; k < chunks; k++) {
+      if ((rc = cached_frame(C, cam, hit_ids != nullptr, w, h, max_depth, flags, band_rows, k,
+                             chunks, C.stream, k == 0)))
+        return rc;
+      HIP_TRY(hipEventRecord(C.ev_chunk[k], C.stream));
+    }
+    for (int k = 0; k < chunks; k++) {
+      const size_t r0 = (size_t)k * band_rows, r1 = std::min((size_t)h, r0 + band_rows);
+      const size_t off = r0 * w, cnt = (r1 - r0) * w;
+      HIP_TRY(hipStreamWaitEvent(C.copy_stream, C.ev_chunk[k], 0));
+      HIP_TRY(hipMemcpyAsync(rgb + 4 * off, C.fb.p + 4 * off, 4 * cnt, hipMemcpyDeviceToHost,
+                             C.copy_stream));
+      if (hit_ids)
+        HIP_TRY(hipMemcpyAsync(hit_ids + off, C.ids.p + off, cnt * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, C.copy_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(C.copy_stream));
+    HIP_TRY(hipStreamSynchronize(C.stream));
+    if (n_rays)
+      HIP_TRY(hipMemcpy(n_rays, C.cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+  }
+  // render; if bounce rays were dropped or the machinery does not fit, again
+  // another way (next_attempt)
   for (;;) {
-    if ((rc = cached_frame(*C, cam, hit_ids != nullptr, w, h, max_depth, flags, 8, 0, 1, nullptr)))
+    rc = cached_frame(C, cam, hit_ids != nullptr, w, h, max_depth, flags, 8, 0, 1, nullptr);
+    if (rc == RT_ERR_CAPACITY && next_attempt(S))
+      continue;
+    if (rc)
       return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
     int over = 0;
@@ -1405,16 +1566,30 @@ int render_cached(const scene_desc *scene, const camera *cam, uint8_t *rgb, int3
       return rc;
     if (!over)
       break;
-    if (S->rays_per_pixel >= 256)
+    if (!next_attempt(S))
       return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
-    S->rays_per_pixel = S->rays_per_pixel * 8 > 256 ? 256 : S->rays_per_pixel * 8;
   }
-  HIP_TRY(hipMemcpy(rgb, C->fb.p, npx * 4, hipMemcpyDeviceToHost));
+  // (a buffer from rt_alloc_host_buffer takes this copy at the full rate of the
+  // link; ordinary pageable memory goes through the runtime's staging)
+  HIP_TRY(hipMemcpy(rgb, C.fb.p, npx * 4, hipMemcpyDeviceToHost));
   if (hit_ids)
-    HIP_TRY(hipMemcpy(hit_ids, C->ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hit_ids, C.ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (n_rays)
-    HIP_TRY(hipMemcpy(n_rays, C->cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_rays, C.cnt.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
+}
+
+// gpu_render_multi, rehearsal only: RT_AMD_LOGICAL_DEVICES=n lets the call take up
+// to n "devices" on a machine with fewer GPUs; slot d then lives on GPU d modulo
+// the GPUs present, with a kept scene, frame buffers and stream of its own, and
+// the band copies, the overflow retry and the ray-count sum run as they would
+// between n GPUs.  Unset (the default), a slot is a GPU.
+int logical_devices() {
+  const char *e = getenv("RT_AMD_LOGICAL_DEVICES");
+  if (!e)
+    return 0;
+  const int n = atoi(e);
+  return n > 0 ? n : 0;
 }
 
 } // namespace
@@ -1422,32 +1597,38 @@ int render_cached(const scene_desc *scene, const camera *cam, uint8_t *rgb, int3
 extern "C" {
 
 void rt_cache_clear(void) {
-  std::lock_guard<std::mutex> lock(g_cache_mutex);
-  int cur = 0;
-  const bool have_dev = hipGetDevice(&cur) == hipSuccess;
   for (int d = 0; d < kMaxCachedDevices; d++) {
-    CachedScene &C = g_cache[d];
-    if (!C.scene && !C.fb.p && !C.ids.p && !C.cnt.p && !C.stream)
-      continue;
-    (void)hipSetDevice(d);
-    rt_scene_destroy(C.scene);
-    C.scene = nullptr;
-    C.fb.release();
-    C.ids.release();
-    C.cnt.release();
-    if (C.stream)
-      (void)hipStreamDestroy(C.stream);
-    C.stream = nullptr;
+    std::lock_guard<std::mutex> lock(g_cache[d].mutex);
+    g_cache[d].drop();
   }
-  if (have_dev)
-    (void)hipSetDevice(cur);
 }
 
 // Scenes the one-call entry points have built so far (diagnostic, for tests of
 // the residency rule; not part of the documented interface).
-uint64_t rt_cache_builds(void) {
-  std::lock_guard<std::mutex> lock(g_cache_mutex);
-  return g_cache_builds;
+uint64_t rt_cache_builds(void) { return g_cache_builds.load(); }
+
+void rt_cache_trust_pointers(int on) { g_trust_pointers.store(on != 0); }
+
+int rt_alloc_host_buffer(size_t bytes, void **out) {
+  if (!out || bytes == 0)
+    return fail(RT_ERR_BAD_ARG, "rt_alloc_host_buffer: null result pointer or zero size");
+  *out = nullptr;
+  int rc = ensure_device();
+  if (rc)
+    return rc;
+  void *p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(RT_ERR_HIP, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  *out = p;
+  return RT_OK;
+}
+
+void rt_free_host_buffer(void *p) {
+  if (p)
+    (void)hipHostFree(p);
 }
 
 int gpu_render_ids(const scene_desc *scene, const camera *cam, uint8_t *rgb,
@@ -1480,13 +1661,18 @@ int gpu_render_multi(const scene_desc *scene, const camera *cam, uint8_t *rgb,
   int visible = 0;
   if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
     return fail(RT_ERR_NO_DEVICE, "no HIP device");
-  if (n_devices < 1 || n_devices > visible || n_devices > kMaxCachedDevices)
-    return fail(RT_ERR_BAD_ARG, "n_devices %d outside 1..%d", n_devices,
-                std::min(visible, kMaxCachedDevices));
+  const int slots = std::min(std::max(visible, logical_devices()), kMaxCachedDevices);
+  if (n_devices < 1 || n_devices > slots)
+    return fail(RT_ERR_BAD_ARG, "n_devices %d outside 1..%d", n_devices, slots);
+  auto gpu_of = [&](int d) { return d % visible; };
   int home = 0;
   HIP_TRY(hipGetDevice(&home));
   const SceneKey key = scene_key(scene);
-  std::lock_guard<std::mutex> lock(g_cache_mutex);
+  // the slots are taken in rising order by every caller, so two calls cannot wait
+  // for each other
+  std::unique_lock<std::mutex> locks[kMaxCachedDevices];
+  for (int d = 0; d < n_devices; d++)
+    locks[d] = std::unique_lock<std::mutex>(g_cache[d].mutex);
   const size_t npx = (size_t)w * h;
   const int bands_total = (h + band_rows - 1) / band_rows;
   CachedScene *C[kMaxCachedDevices] = {};
@@ -1494,51 +1680,57 @@ int gpu_render_multi(const scene_desc *scene, const camera *cam, uint8_t *rgb,
     // the scene on every device (the builds of different devices run one after
     // the other on this thread; kept scenes cost nothing)
     for (int d = 0; d < n_devices; d++) {
-      HIP_TRY(hipSetDevice(d));
-      int r = cached_scene(scene, key, &C[d]);
+      HIP_TRY(hipSetDevice(gpu_of(d)));
+      C[d] = &g_cache[d];
+      int r = cached_scene(*C[d], scene, key);
       if (r)
         return r;
       if (!C[d]->stream)
         HIP_TRY(hipStreamCreateWithFlags(&C[d]->stream, hipStreamNonBlocking));
-      if (d > 0) {
+      if (gpu_of(d) != gpu_of(0)) {
         int can = 0;
-        HIP_TRY(hipDeviceCanAccessPeer(&can, 0, d));
+        HIP_TRY(hipDeviceCanAccessPeer(&can, gpu_of(0), gpu_of(d)));
         if (can) { // device 0 reads its peers' bands directly over xGMI
-          hipError_t e = hipSetDevice(0) == hipSuccess ? hipDeviceEnablePeerAccess(d, 0)
-                                                       : hipErrorInvalidDevice;
+          hipError_t e = hipSetDevice(gpu_of(0)) == hipSuccess
+                             ? hipDeviceEnablePeerAccess(gpu_of(d), 0)
+                             : hipErrorInvalidDevice;
           if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-            return fail(RT_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", d, hipGetErrorString(e));
+            return fail(RT_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", gpu_of(d),
+                        hipGetErrorString(e));
           (void)hipGetLastError();
         }
       }
     }
     for (;;) {
       // every device renders its bands on its own stream
+      bool short_of_memory = false;
       for (int d = 0; d < n_devices; d++) {
-        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipSetDevice(gpu_of(d)));
         int r = cached_frame(*C[d], cam, hit_ids != nullptr, w, h, max_depth, 0, band_rows, d,
                              n_devices, C[d]->stream);
-        if (r)
+        if (r == RT_ERR_CAPACITY)
+          short_of_memory = true;
+        else if (r)
           return r;
       }
       // the bands travel to device 0: one peer copy per band, on the owner's
       // stream (behind its render), so the copies of different devices overlap
-      for (int d = 1; d < n_devices; d++) {
-        HIP_TRY(hipSetDevice(d));
+      for (int d = 1; d < n_devices && !short_of_memory; d++) {
+        HIP_TRY(hipSetDevice(gpu_of(d)));
         for (int b = d; b < bands_total; b += n_devices) {
           const size_t r0 = (size_t)b * band_rows;
           const size_t r1 = std::min((size_t)h, r0 + band_rows);
           const size_t off = r0 * w, cnt = (r1 - r0) * w;
-          HIP_TRY(hipMemcpyPeerAsync(C[0]->fb.p + 4 * off, 0, C[d]->fb.p + 4 * off, d, 4 * cnt,
-                                     C[d]->stream));
+          HIP_TRY(hipMemcpyPeerAsync(C[0]->fb.p + 4 * off, gpu_of(0), C[d]->fb.p + 4 * off,
+                                     gpu_of(d), 4 * cnt, C[d]->stream));
           if (hit_ids)
-            HIP_TRY(hipMemcpyPeerAsync(C[0]->ids.p + off, 0, C[d]->ids.p + off, d,
+            HIP_TRY(hipMemcpyPeerAsync(C[0]->ids.p + off, gpu_of(0), C[d]->ids.p + off, gpu_of(d),
                                        sizeof(int32_t) * cnt, C[d]->stream));
         }
       }
-      bool over = false;
+      bool over = short_of_memory;
       for (int d = 0; d < n_devices; d++) {
-        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipSetDevice(gpu_of(d)));
         HIP_TRY(hipStreamSynchronize(C[d]->stream));
         int o = 0;
         int r = rt_scene_queue_overflowed(C[d]->scene, &o);
@@ -1548,12 +1740,14 @@ int gpu_render_multi(const scene_desc *scene, const camera *cam, uint8_t *rgb,
       }
       if (!over)
         break;
-      if (C[0]->scene->rays_per_pixel >= 256)
-        return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
+      // every device renders the frame again the same other way
+      bool more = true;
       for (int d = 0; d < n_devices; d++)
-        C[d]->scene->rays_per_pixel = std::min(256, C[d]->scene->rays_per_pixel * 8);
+        more = next_attempt(C[d]->scene) && more;
+      if (!more)
+        return fail(RT_ERR_CAPACITY, "bounce-ray queue overflowed; image is incomplete");
     }
-    HIP_TRY(hipSetDevice(0));
+    HIP_TRY(hipSetDevice(gpu_of(0)));
     HIP_TRY(hipMemcpy(rgb, C[0]->fb.p, npx * 4, hipMemcpyDeviceToHost));
     if (hit_ids)
       HIP_TRY(hipMemcpy(hit_ids, C[0]->ids.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1561,7 +1755,7 @@ int gpu_render_multi(const scene_desc *scene, const camera *cam, uint8_t *rgb,
       *n_rays = 0;
       for (int d = 0; d < n_devices; d++) {
         uint64_t v = 0;
-        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipSetDevice(gpu_of(d)));
         HIP_TRY(hipMemcpy(&v, C[d]->cnt.p, sizeof v, hipMemcpyDeviceToHost));
         *n_rays += v;
       }
@@ -1585,9 +1779,36 @@ int gpu_check_intersection(rt_scene *S, int64_t n, const float *orig,
   if (!orig || !dir || !kind || !index || !P)
     return fail(RT_ERR_BAD_ARG, "NULL ray or result array");
   HIP_TRY(hipSetDevice(S->device));
+  const size_t un = (size_t)n;
+  rt::CheckArgs a;
+  a.n = (long)n;
+  if (un <= kCheckPinnedRays) {
+    // A few rays (the reference's callers ask for one per call): the kernel reads
+    // the rays from, and writes the answers to, a small block of pinned host
+    // memory that the scene keeps mapped into the device, so the call is a launch
+    // and a wait; five small copies cost several times that.
+    if (!S->chk_pin) {
+      HIP_TRY(hipHostMalloc((void **)&S->chk_pin, kCheckPinnedRays * 11 * sizeof(float),
+                            hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer((void **)&S->chk_pin_dev, S->chk_pin, 0));
+    }
+    float *h = S->chk_pin, *d = S->chk_pin_dev;
+    memcpy(h, orig, 3 * un * sizeof(float));
+    memcpy(h + 3 * un, dir, 3 * un * sizeof(float));
+    a.orig = d;
+    a.dir = d + 3 * un;
+    a.P = d + 6 * un;
+    a.kind = (int32_t *)(d + 9 * un);
+    a.index = (int32_t *)(d + 10 * un);
+    HIP_TRY(rt::launch_check(S->dev(), a, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    memcpy(P, h + 6 * un, 3 * un * sizeof(float));
+    memcpy(kind, h + 9 * un, un * sizeof(int32_t));
+    memcpy(index, h + 10 * un, un * sizeof(int32_t));
+    return RT_OK;
+  }
   // staging kept by the scene (grow-only): origins then directions; kinds then
   // indices
-  const size_t un = (size_t)n;
   if (S->chk_in.n < 6 * un) {
     HIP_TRY(S->chk_in.alloc(6 * un));
     HIP_TRY(S->chk_P.alloc(3 * un));
@@ -1595,8 +1816,6 @@ int gpu_check_intersection(rt_scene *S, int64_t n, const float *orig,
   }
   HIP_TRY(hipMemcpy(S->chk_in.p, orig, 3 * un * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S->chk_in.p + 3 * un, dir, 3 * un * sizeof(float), hipMemcpyHostToDevice));
-  rt::CheckArgs a;
-  a.n = (long)n;
   a.orig = S->chk_in.p;
   a.dir = S->chk_in.p + 3 * un;
   a.kind = S->chk_out.p;
@@ -1609,21 +1828,55 @@ int gpu_check_intersection(rt_scene *S, int64_t n, const float *orig,
   return RT_OK;
 }
 
+// renderer.cpp:106-110 for n (lang, colour) pairs: host arrays in, host arrays out.
+int gpu_specular_terms(int64_t n, const float *lang, const uint8_t *color, float *strength,
+                       uint8_t *specular) {
+  if (n < 0)
+    return fail(RT_ERR_BAD_ARG, "n < 0");
+  if (n == 0)
+    return RT_OK;
+  if (!lang || !color || !strength || !specular)
+    return fail(RT_ERR_BAD_ARG, "NULL input or result array");
+  int rc = ensure_device();
+  if (rc)
+    return rc;
+  const size_t un = (size_t)n;
+  DevBuf<float> d_lang, d_str;
+  DevBuf<uint8_t> d_col, d_spec;
+  HIP_TRY(d_lang.alloc(un));
+  HIP_TRY(d_str.alloc(un));
+  HIP_TRY(d_col.alloc(un));
+  HIP_TRY(d_spec.alloc(un));
+  HIP_TRY(hipMemcpy(d_lang.p, lang, un * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_col.p, color, un, hipMemcpyHostToDevice));
+  HIP_TRY(rt::launch_specular((long)n, d_lang.p, d_col.p, d_str.p, d_spec.p, nullptr));
+  HIP_TRY(hipMemcpy(strength, d_str.p, un * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(specular, d_spec.p, un, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
 // One ray through the scene that gpu_render* would keep for these arrays
 // (renderer.hpp:21-23 as the reference's own callers use it: the same arrays,
-// one ray per call).  The first call uploads; later calls with unchanged arrays
-// only hash them and launch.
+// one ray per call).  The first call uploads; later calls with unchanged
+// geometry only hash it (rt_cache_trust_pointers: not even that) and launch.
+// A scene that render() left resident serves these calls as it is, and the other
+// way round a render() after them rebuilds once (it needs colours and lights).
 int gpu_check_intersection_arrays(const scene_desc *scene, const float *orig, const float *dir,
                                   int32_t *kind, int32_t *index, float *P) {
   int rc = check_scene_desc(scene, false);
-  if (rc)
+  if (rc || (rc = ensure_device()))
     return rc;
-  const SceneKey key = scene_key(scene);
-  std::lock_guard<std::mutex> lock(g_cache_mutex);
-  CachedScene *C = nullptr;
-  if ((rc = cached_scene(scene, key, &C, false)))
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxCachedDevices)
+    return fail(RT_ERR_UNSUPPORTED, "device %d: only devices 0..%d keep a scene", dev,
+                kMaxCachedDevices - 1);
+  const SceneKey key = scene_key(scene, true);
+  CachedScene &C = g_cache[dev];
+  std::lock_guard<std::mutex> lock(C.mutex);
+  if ((rc = cached_scene(C, scene, key, false)))
     return rc;
-  return gpu_check_intersection(C->scene, 1, orig, dir, kind, index, P);
+  return gpu_check_intersection(C.scene, 1, orig, dir, kind, index, P);
 }
 
 } // extern "C"

@@ -168,5 +168,8 @@ hipError_t launch_gather_leaves(const float4 *sph_geo, const uchar4 *col_sph,
 hipError_t launch_gather_tri_leaves(const TriRec *tri, const int32_t *leaf_idx, TriLeaf *leaf,
                                     int n, hipStream_t st);
 hipError_t launch_check(const SceneDev &sc, const CheckArgs &a, hipStream_t st);
+// renderer.cpp:106-110 on n caller-supplied (lang, colour) pairs, device arrays
+hipError_t launch_specular(long n, const float *lang, const uint8_t *color, float *strength,
+                           uint8_t *specular, hipStream_t st);
 
 } // namespace rt

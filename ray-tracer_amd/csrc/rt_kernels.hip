@@ -574,8 +574,34 @@ __global__ __launch_bounds__(256) void k_check(SceneDev sc, CheckArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// k_specular — the specular term of renderer.cpp:106-110 on caller-supplied
+// values, one per lane: strength = pow(lang, 20) as the shading computes it
+// (pow20 above), specular = (unsigned char)(colour * strength).  Exists so that
+// this one expression, whose libm call the device replaces by five multiplies,
+// can be checked value by value.
+// ---------------------------------------------------------------------------
+__global__ void k_specular(long n, const float *lang, const uint8_t *color, float *strength,
+                           uint8_t *specular) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const float s = pow20(lang[i]);
+  strength[i] = s;
+  specular[i] = (uint8_t)((uint32_t)((float)color[i] * s) & 0xffu); // renderer.cpp:108-110
+}
+
+// ---------------------------------------------------------------------------
 // Launchers (host)
 // ---------------------------------------------------------------------------
+hipError_t launch_specular(long n, const float *lang, const uint8_t *color, float *strength,
+                           uint8_t *specular, hipStream_t st) {
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(k_specular, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, lang,
+                     color, strength, specular);
+  return hipGetLastError();
+}
+
 hipError_t launch_prep_scene(const PrepArgs &a, hipStream_t st) {
   int n = a.s_pad > a.t_size ? a.s_pad : a.t_size;
   if (n <= 0)

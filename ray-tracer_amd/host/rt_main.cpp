@@ -7,7 +7,9 @@
 // reference's 2560x1440, renderer.hpp:10-11), -depth D, -o <ppm path>,
 // -keep-spheres (use the file's spheres), -phantoms (reference-compatible blank
 // lines), -repeat N (call gpu_render N times and report each; the first call of
-// a process also pays for the HIP context and code-object load).  There is no viewer here: without -n the frame is rendered and dropped.
+// a process also pays for the HIP context and code-object load), -pageable (keep
+// the frame buffer in ordinary memory, as the reference's new[] at main.cpp:91
+// does, instead of taking it from rt_alloc_host_buffer).  There is no viewer here: without -n the frame is rendered and dropped.
 #include "../../include/rt_amd.h"
 #include "../../include/rt_host.h"
 
@@ -79,27 +81,40 @@ int main(int argc, char **argv) {
   camera cam;
   rt_camera_default(&cam); // fov 90, main.cpp:88
 
-  std::vector<uint8_t> fb((size_t)4 * w * h);
+  // the copy back into page-locked memory runs at the rate of the link
+  const size_t fb_bytes = (size_t)4 * w * h;
+  std::vector<uint8_t> pageable;
+  void *locked = nullptr;
+  if (flag(argc, argv, "-pageable") || rt_alloc_host_buffer(fb_bytes, &locked) != RT_OK) {
+    locked = nullptr;
+    pageable.resize(fb_bytes);
+  }
+  uint8_t *const fb = locked ? (uint8_t *)locked : pageable.data();
+  const bool pinned = locked != nullptr;
   uint64_t rays = 0;
   for (int it = 0; it < (repeat > 0 ? repeat : 1); it++) {
     auto t0 = std::chrono::steady_clock::now();
-    rc = gpu_render_ids(&s, &cam, fb.data(), nullptr, &rays, w, h, depth);
+    rc = gpu_render_ids(&s, &cam, fb, nullptr, &rays, w, h, depth);
     double ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc != RT_OK) {
       fprintf(stderr, "gpu_render failed (%d): %s\n", rc, rt_last_error());
+      rt_free_host_buffer(locked);
       rt_host_free_scene(&hs);
       return 1;
     }
     fprintf(stderr, "%dx%d, %d triangles, %d spheres, %d lights, depth %d: %llu rays in %.1f ms "
-                    "(upload + render + copy-back)\n",
-            w, h, s.t_size, s.s_size, s.l_size, depth, (unsigned long long)rays, ms);
+                    "(upload + render + copy-back%s)\n",
+            w, h, s.t_size, s.s_size, s.l_size, depth, (unsigned long long)rays, ms,
+            pinned ? ", page-locked frame buffer" : "");
   }
-  if (flag(argc, argv, "-n") && rt_host_write_ppm(out, fb.data(), w, h) != 0) { // main.cpp:155-173
+  if (flag(argc, argv, "-n") && rt_host_write_ppm(out, fb, w, h) != 0) { // main.cpp:155-173
     fprintf(stderr, "cannot write %s\n", out);
+    rt_free_host_buffer(locked);
     rt_host_free_scene(&hs);
     return 1;
   }
+  rt_free_host_buffer(locked);
   rt_host_free_scene(&hs);
   return 0;
 }

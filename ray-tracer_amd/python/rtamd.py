@@ -193,6 +193,13 @@ def lib() -> C.CDLL:
     L.rt_cache_builds.restype = C.c_uint64
     L.gpu_check_intersection.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_cache_trust_pointers.argtypes = [C.c_int]
+    L.rt_cache_trust_pointers.restype = None
+    L.rt_alloc_host_buffer.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.rt_free_host_buffer.argtypes = [C.c_void_p]
+    L.rt_free_host_buffer.restype = None
+    L.rt_scene_set_arena_limit.argtypes = [C.c_void_p, C.c_uint64]
+    L.gpu_specular_terms.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -216,6 +223,41 @@ def set_screen(mode):
     its scene inside the call): "off" (plain every-ray-every-sphere loop), "auto"
     (default), "beam" or "bvh"; True/False mean "auto"/"off"."""
     lib().rt_set_screen(_mode(mode))
+
+
+def specular_terms(lang: np.ndarray, color: np.ndarray):
+    """gpu_specular_terms: (strength float32, specular uint8) of renderer.cpp:106-110 as
+    the device computes them."""
+    lang = np.ascontiguousarray(lang, np.float32).reshape(-1)
+    color = np.ascontiguousarray(color, np.uint8).reshape(-1)
+    assert len(lang) == len(color)
+    strength = np.empty(len(lang), np.float32)
+    spec = np.empty(len(lang), np.uint8)
+    _check(lib().gpu_specular_terms(len(lang), lang.ctypes.data, color.ctypes.data,
+                                    strength.ctypes.data, spec.ctypes.data))
+    return strength, spec
+
+
+class HostBuffer:
+    """rt_alloc_host_buffer / rt_free_host_buffer: page-locked host memory as a
+    numpy uint8 array (``.array``) that stays valid until close()."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        _check(lib().rt_alloc_host_buffer(nbytes, C.byref(self.ptr)))
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self.ptr.value))
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib().rt_free_host_buffer(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def render_unlit(scene: "Scene", w: int, h: int, cam: Optional[Camera] = None) -> np.ndarray:
@@ -366,6 +408,10 @@ class DeviceScene:
         n = C.c_uint64(0)
         _check(lib().rt_noalloc_scratch_needed(self.handle, C.byref(f), C.byref(n)))
         return int(n.value)
+
+    def set_arena_limit(self, max_bytes: int):
+        """rt_scene_set_arena_limit: cap on the device memory of the bounce machinery."""
+        _check(lib().rt_scene_set_arena_limit(self.handle, max_bytes))
 
     def set_rays_per_pixel(self, n: int):
         """rt_scene_set_rays_per_pixel: bounce-queue capacity of later frames."""

@@ -206,6 +206,44 @@ def test_queue_capacity_grows_when_rays_multiply(oracle):
             ds.set_rays_per_pixel(257)
 
 
+def test_bounce_machinery_that_does_not_fit_leaves_a_usable_scene(oracle):
+    """A frame whose bounce machinery exceeds the scene's limit (or the device's
+    memory: same code) fails with RT_ERR_CAPACITY and leaves the scene without
+    any machinery; a smaller frame afterwards starts afresh and is complete."""
+    import torch
+    sc = material_scene(57)
+    w, h = 256, 144
+    fo, io, no = oracle.render(sc, w, h, max_depth=4)
+    dev = torch.device("cuda", 0)
+    fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def small():
+        fb.zero_()
+        cnt.zero_()
+        ds.render_device(fb.data_ptr(), None, w, h, max_depth=4, dev_ray_count=cnt.data_ptr())
+        torch.cuda.synchronize()
+        assert not ds.queue_overflowed()
+        assert np.array_equal(fb.cpu().numpy(), fo) and int(cnt.item()) == no
+
+    with rtamd.DeviceScene(sc) as ds:
+        assert ds.describe()["one_launch"]
+        small()
+        ds.set_arena_limit(1 << 30)
+        small()                               # what it has already fits
+        with pytest.raises(rtamd.RtError) as e:   # per-wave stacks for 63 levels: > 1 GiB
+            ds.render_device(fb.data_ptr(), None, w, h, max_depth=63)
+        assert e.value.code == rtamd.RT_ERR_CAPACITY
+        assert not ds.queue_overflowed()      # reads no freed flag
+        small()
+        small()
+        ds.set_arena_limit(0)
+        ds.render_device(fb.data_ptr(), None, w, h, max_depth=63)
+        torch.cuda.synchronize()
+        assert not ds.queue_overflowed()
+        assert np.array_equal(fb.cpu().numpy(), oracle.render(sc, w, h, max_depth=63)[0])
+
+
 def test_invalid_materials_rejected():
     sc = golden_scenes.mixed_scene()
     sc.mat_sphere = np.zeros((sc.s_size, 4), np.float32)

@@ -83,3 +83,87 @@ def test_shim_check_intersection_per_ray_keeps_the_scene(oracle):
             assert idx.value == -7          # untouched on a miss, renderer.cpp:179-180
     assert builds() == b0 + 1
     rtamd.lib().rt_cache_clear()
+
+
+def test_alternating_render_and_check_intersection_builds_once(oracle):
+    """The reference's two symbols called in turn by one host with the same arrays
+    (render() passes colours and lights, check_intersection() cannot): the scene
+    that render() left resident serves the geometric queries, ten rounds, one
+    build."""
+    import os
+    shim = C.CDLL(os.path.join(rtamd.PKG_DIR, "host", "librt_shim.so"))
+    chk = getattr(shim, "_Z18check_intersectionPfiS_S_iS_PiS_S_")
+    chk.restype = C.c_int
+    ren = getattr(shim, "_Z6renderPhiPfS_iS0_S0_S_iS0_i")
+    ren.restype = None
+    sc = golden_scenes.mixed_scene(seed=64, n_spheres=70, n_tris=9)
+    o, d = golden_scenes.random_rays(10, seed=6)
+    ko, io, Po = oracle.check_intersection(sc, o, d)
+    fo = oracle.render(sc, 2560, 1440)[0]        # the shim's compiled-in frame size
+    fb = np.zeros((1440, 2560, 4), np.uint8)
+    vp = C.c_void_p
+    rtamd.lib().rt_cache_clear()
+    b0 = builds()
+    for r in range(10):
+        ren(vp(fb.ctypes.data), 90, vp(sc.tris.ctypes.data), vp(sc.color_tri.ctypes.data),
+            sc.t_size, vp(sc.spheres.ctypes.data), vp(sc.radius.ctypes.data),
+            vp(sc.color_sphere.ctypes.data), sc.s_size, vp(sc.lights.ctypes.data), sc.l_size)
+        if r in (0, 9):
+            assert np.array_equal(fb, fo)
+        P = np.zeros(3, np.float32)
+        idx = C.c_int(-7)
+        k = chk(vp(sc.tris.ctypes.data), sc.t_size, vp(sc.spheres.ctypes.data),
+                vp(sc.radius.ctypes.data), sc.s_size, vp(P.ctypes.data), C.byref(idx),
+                vp(o[r].ctypes.data), vp(d[r].ctypes.data))
+        assert k == ko[r]
+        if k:
+            assert idx.value == io[r] and np.array_equal(P.view(np.uint32), Po[r].view(np.uint32))
+    assert builds() == b0 + 1
+    # the other way round: queries first build a geometry-only scene, the first
+    # render() replaces it (it needs colours and lights), then nothing more
+    rtamd.lib().rt_cache_clear()
+    b0 = builds()
+    for r in range(3):
+        P = np.zeros(3, np.float32)
+        idx = C.c_int(-7)
+        chk(vp(sc.tris.ctypes.data), sc.t_size, vp(sc.spheres.ctypes.data),
+            vp(sc.radius.ctypes.data), sc.s_size, vp(P.ctypes.data), C.byref(idx),
+            vp(o[r].ctypes.data), vp(d[r].ctypes.data))
+        ren(vp(fb.ctypes.data), 90, vp(sc.tris.ctypes.data), vp(sc.color_tri.ctypes.data),
+            sc.t_size, vp(sc.spheres.ctypes.data), vp(sc.radius.ctypes.data),
+            vp(sc.color_sphere.ctypes.data), sc.s_size, vp(sc.lights.ctypes.data), sc.l_size)
+    assert builds() == b0 + 2
+    assert np.array_equal(fb, fo)
+    rtamd.lib().rt_cache_clear()
+
+
+def test_trusted_pointers_skip_the_hash_and_locked_buffers_receive_the_frame(oracle):
+    """rt_cache_trust_pointers: same pointers and sizes are the same scene, edits in
+    place go unnoticed (that is the contract).  rt_alloc_host_buffer: a page-locked
+    frame buffer receives the same bytes."""
+    sc = golden_scenes.mixed_scene(seed=65, n_spheres=40, n_tris=8)
+    L = rtamd.lib()
+    L.rt_cache_clear()
+    fo = oracle.render(sc, 320, 200)[0]
+    L.rt_cache_trust_pointers(1)
+    try:
+        b0 = builds()
+        with rtamd.HostBuffer(320 * 200 * 4) as hb:
+            fb = hb.array.reshape(200, 320, 4)
+            d = sc.desc()
+            cam = rtamd.default_camera()
+            for _ in range(3):
+                fb[:] = 0
+                rtamd._check(L.gpu_render(C.byref(d), C.byref(cam), fb.ctypes.data, 320, 200, 1))
+                assert np.array_equal(fb, fo)
+            assert builds() == b0 + 1
+            sc.spheres[5, 2] += np.float32(2.0)  # in place: not noticed while trusted
+            rtamd._check(L.gpu_render(C.byref(d), C.byref(cam), fb.ctypes.data, 320, 200, 1))
+            assert builds() == b0 + 1 and np.array_equal(fb, fo)
+            del fb
+    finally:
+        L.rt_cache_trust_pointers(0)
+    fb2 = rtamd.render_plain(sc, 320, 200)   # hashed again: the edit is seen
+    assert np.array_equal(fb2, oracle.render(sc, 320, 200)[0])
+    assert not np.array_equal(fb2, fo)
+    L.rt_cache_clear()

@@ -19,6 +19,8 @@ import os
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 root = sys.argv[1]
 STAGE_OF = (("k_render<", "primary"), ("k_trace", "bounce"), ("k_walk<", "bounce"),
             ("k_shade", "bounce"), ("k_bounce<", "bounce"), ("k_compose", "compose"))
@@ -106,6 +108,12 @@ for st in ("primary", "bounce", "compose"):
     # reads high on short dispatches, so it is capped at the maximum clock)
     clock = min(2.4, gui / (ms * 1e-3) / 1e9) if ms > 0 and gui > 0 else 2.4
     hbm = (v.get("FETCH_SIZE", 0.0) * 2 + v.get("WRITE_SIZE", 0.0)) * 1024
+    # mean resident waves per SIMD over the stage: wave-cycles (the counter ticks once
+    # per four cycles) over the cycles of the launch on the chip's 1024 SIMDs; and
+    # the same over the cycles in which a shader engine had any wave at all
+    occ = v.get("SQ_WAVE_CYCLES", 0.0) * 4 / max(1.0, ms * 1e-3 * clock * 1e9 * 1024)
+    lds_active = v.get("SQ_LDS_IDX_ACTIVE", 0.0)
+    lds_conflict = v.get("SQ_LDS_BANK_CONFLICT", 0.0)
     e = {
         "kernels": sorted(kernels_of[st]), "ms": ms, "valu_wave_insts": insts,
         "lanes_per_valu_inst": lanes, "clock_ghz": clock, "hbm_bytes": hbm,
@@ -117,6 +125,12 @@ for st in ("primary", "bounce", "compose"):
         "salu_insts": v.get("SQ_INSTS_SALU", 0.0), "smem_insts": v.get("SQ_INSTS_SMEM", 0.0),
         "vmem_rd_insts": v.get("SQ_INSTS_VMEM_RD", 0.0), "vmem_wr_insts": v.get("SQ_INSTS_VMEM_WR", 0.0),
         "lds_insts": v.get("SQ_INSTS_LDS", 0.0), "gui_active_cycles_per_xcd": gui,
+        "occupancy_waves_per_simd": occ,
+        "waves_per_busy_cycle": v.get("SQ_WAVE_CYCLES", 0.0) / max(1.0, v.get("SQ_BUSY_CYCLES", 1.0)),
+        "lds_idx_active_cycles": lds_active, "lds_bank_conflict_cycles": lds_conflict,
+        "lds_bank_conflict_frac": lds_conflict / lds_active if lds_active > 0 else None,
+        "lds_addr_conflict_cycles": v.get("SQ_LDS_ADDR_CONFLICT", 0.0),
+        "lds_wait_inst_frac": v.get("SQ_WAIT_INST_LDS", 0.0) / wave_cyc,
     }
     stages[st] = e
     lane_ops = insts * lanes
@@ -129,17 +143,23 @@ for st in ("primary", "bounce", "compose"):
           f"{e['wait_inst_any_frac']:.2f}, issuing {e['active_inst_any_frac']:.2f} of wave time;  "
           f"VMEM rd {e['vmem_rd_insts']:.3g} wr {e['vmem_wr_insts']:.3g}  LDS {e['lds_insts']:.3g}  "
           f"SALU {e['salu_insts']:.3g};  HBM {hbm / 1e6:.1f} MB ({hbm / max(ms, 1e-9) / 1e6:.0f} GB/s)")
+    cf = e["lds_bank_conflict_frac"]
+    print(f"            occupancy {occ:.2f} waves per SIMD (mean over the stage);  LDS: "
+          f"{lds_active:.4g} active cycles, {lds_conflict:.4g} bank-conflict cycles"
+          + (f" = {cf:.4f} of them" if cf is not None else " (pass not run)"))
 total_ms = sum(e["ms"] for e in stages.values())
 print(f"   frame: {total_ms:.3f} ms of kernel time ({frames_seen.get('ms', 0)} frames traced)")
 
 if len(sys.argv) > 4:
     workload, path, one_launch = sys.argv[2], sys.argv[3], int(sys.argv[4])
     data = json.load(open(path)) if os.path.exists(path) else {}
+    import bench
     data[workload] = {
+        "source_sha": bench.kernel_source_sha(),   # the build these counts belong to
         "one_launch": one_launch, "frames_profiled": frames_seen.get("ms", 0),
         "frame_kernel_ms": total_ms, "stages": stages,
         "how": "tools/profile.sh: rocprofv3 --kernel-trace --stats, then separate --pmc passes "
-               "(SQ, SQ2+GRBM, FETCH_SIZE, WRITE_SIZE) of bench.py --frames-in-flight 1; sums "
+               "(SQ, SQ2+GRBM, LDS, FETCH_SIZE, WRITE_SIZE) of bench.py --frames-in-flight 1; sums "
                "over a stage's dispatches divided by the frames profiled"}
     json.dump(data, open(path, "w"), indent=1)
     print(f"   -> {path} [{workload}]")
