@@ -301,7 +301,9 @@ static float phong_light(const hit_info *hi, const float dir[3],
 /* ---- the bounce extension (NOT in the reference; parity unpinned) ----------
  * Active only when max_depth > 1.  Then a hit on a primitive with material
  * (kr, kt, ior) at path weight w:
- *   - local Phong light is weighted by wl = w * ((1 - kr) - kt)
+ *   - local Phong light is weighted by wl = w * ((1 - kr) - kt); below the
+ *     primary hit a light whose three integer contributions trunc(fColor*angle*wl)
+ *     are all zero casts no shadow ray (the ray could not change the pixel)
  *   - if depth < max_depth and w*kr >= 2^-8: a mirror ray from P along
  *     normalize(reflect(dir, n)) with weight w*kr
  *   - if depth < max_depth and w*kt >= 2^-8: a refracted ray (Snell, ior;
@@ -405,6 +407,13 @@ static uint64_t shade_pixel(const scene_desc *sc, const camera *cam, int w,
         float fColor[3], rayDir[3], P1[3];
         int dummy;
         float angle = phong_light(&hi, r.d, sc->lights + l * 3, fColor, rayDir);
+        /* extension: below the primary hit a light that cannot add one unit to
+         * any channel casts no shadow ray (nothing could be added whatever the
+         * ray finds); the primary hit always casts it, renderer.cpp:119 */
+        if (r.depth > 1 && (uint32_t)((fColor[0] * angle) * wl) == 0 &&
+            (uint32_t)((fColor[1] * angle) * wl) == 0 &&
+            (uint32_t)((fColor[2] * angle) * wl) == 0)
+          continue;
         rays++;
         if (oracle_check_intersection(sc->tris, sc->t_size, sc->spheres,
                                       sc->radius, sc->s_size, P1, &dummy, hi.P,

@@ -171,7 +171,8 @@ __device__ __forceinline__ float phong_light(const Surface &s, const Hit &h,
 // Material bounces (an extension; the reference has none)
 // ---------------------------------------------------------------------------
 // A hit on a primitive with material (kr, kt, ior) at path weight w:
-//   - its Phong light is weighted by wl = w * ((1 - kr) - kt)
+//   - its Phong light is weighted by wl = w * ((1 - kr) - kt); below the primary
+//     hit a light whose three integer contributions are all zero casts no shadow ray
 //   - if depth < max_depth and w*kr >= 2^-8: a mirror ray from P along
 //     normalize(reflect(dir, n)), weight w*kr
 //   - if depth < max_depth and w*kt >= 2^-8: a refracted ray (Snell; total
@@ -298,20 +299,24 @@ shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
         angle = phong_light(s, h, dx, dy, dz, light, fColor, lx, ly, lz);
         dist = length3(light.x - h.Px, light.y - h.Py, light.z - h.Pz);
       }
+      float a0 = fColor[0] * angle, a1 = fColor[1] * angle, a2 = fColor[2] * angle;
+      if (MATERIALS) {
+        a0 *= wl;
+        a1 *= wl;
+        a2 *= wl;
+      }
+      // Below the primary hit a light that cannot add one unit to any channel casts
+      // no shadow ray (nothing would be added whatever the ray found); the primary
+      // hit always casts it, as renderer.cpp:119 does.
+      const bool cast = lit && (PRIMARY || ((uint32_t)a0 | (uint32_t)a1 | (uint32_t)a2) != 0);
       // renderer.cpp:119: shadow ray from exactly P, no distance limit.  All
       // shadow rays of the wave aim at the light: that is the beam's apex.
-      Hit sh = trace<false, true, BEAM, VERIFY, TRI_TREE>(sc, lit, h.Px, h.Py, h.Pz, lx, ly,
+      Hit sh = trace<false, true, BEAM, VERIFY, TRI_TREE>(sc, cast, h.Px, h.Py, h.Pz, lx, ly,
                                                 lz, light.x, light.y, light.z,
                                                 dist, st, lds_stack);
-      if (lit) {
+      if (cast) {
         n_rays++;
         if (sh.kind == 0) {
-          float a0 = fColor[0] * angle, a1 = fColor[1] * angle, a2 = fColor[2] * angle;
-          if (MATERIALS) {
-            a0 *= wl;
-            a1 *= wl;
-            a2 *= wl;
-          }
           if (PRIMARY) {
             fb0 = accumulate_u8(fb0, a0);
             fb1 = accumulate_u8(fb1, a1);

@@ -136,9 +136,18 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
     for (int l = 0; l < sc.l_size; l++) { // renderer.cpp:82
       float fColor[3] = {0, 0, 0};
       float lx = 0, ly = 0, lz = 0, angle = 0;
-      bool blocked = false;
-      if (lit) {
+      if (lit)
         angle = phong_light(sf, h, dx, dy, dz, sc.lights[l], fColor, lx, ly, lz);
+      const uint32_t c0 = (uint32_t)((fColor[0] * angle) * wl),
+                     c1 = (uint32_t)((fColor[1] * angle) * wl),
+                     c2 = (uint32_t)((fColor[2] * angle) * wl);
+      const uint32_t packed = (c0 & 0x3ffu) | ((c1 & 0x3ffu) << 10) | ((c2 & 0x3ffu) << 20);
+      // a light that cannot add one unit to any channel casts no shadow ray: whatever
+      // the ray found, nothing would be added (on the bench frame that is three in
+      // five of the bounce hits' lights: surfaces that face away from the light)
+      const bool cast = lit && packed != 0;
+      bool blocked = false;
+      if (cast) {
         // renderer.cpp:119: the shadow ray starts exactly at P; its triangles here
         float len_t = RT_INF, tx, ty, tz;
         int idx_t = -1;
@@ -147,11 +156,7 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
         if (blocked)
           out.n_rays++; // traced to the end here; the others are counted by the walk
       }
-      const uint32_t c0 = (uint32_t)((fColor[0] * angle) * wl),
-                     c1 = (uint32_t)((fColor[1] * angle) * wl),
-                     c2 = (uint32_t)((fColor[2] * angle) * wl);
-      const uint32_t packed = (c0 & 0x3ffu) | ((c1 & 0x3ffu) << 10) | ((c2 & 0x3ffu) << 20);
-      sp = stack_push(stack, sp, cap, overflow, lit && !blocked,
+      sp = stack_push(stack, sp, cap, overflow, cast && !blocked,
                       make_float4(h.Px, h.Py, h.Pz, __uint_as_float(pixel | RT_ITEM_SHADOW)),
                       make_float4(lx, ly, lz, __uint_as_float(packed)));
     }
@@ -194,9 +199,22 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
 // wait for them) was more than twice as many.  For the stores to stay in range a
 // lane never enters a visit with more than TRACE_PARK_FULL parked leaves: the wave
 // works the parked leaves off first (all lanes together, as at every refill).
-constexpr int TRACE_PARK_ROWS = 9;
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 5
+#endif
+#ifndef RT_TRACE_STACK_ROWS
+#define RT_TRACE_STACK_ROWS LDS_STACK_ROWS
+#endif
+#ifndef RT_TRACE_PARK_ROWS
+#define RT_TRACE_PARK_ROWS 9
+#endif
+constexpr int TRACE_STACK_ROWS = RT_TRACE_STACK_ROWS;
+constexpr int TRACE_PARK_ROWS = RT_TRACE_PARK_ROWS;
 constexpr int TRACE_PARK_FULL = TRACE_PARK_ROWS - BVH_WIDTH;
-static_assert((LDS_STACK_ROWS + TRACE_PARK_ROWS) * 1024 < 32768,
+// A walk steps aside for a batch of shading into its own column (k_trace): sixteen
+// rows from its stack height on, and the column's last row.
+constexpr int TRACE_SAVE_MAX_SP = TRACE_STACK_ROWS + TRACE_PARK_ROWS - 1 - 16;
+static_assert((TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 1024 < 32768,
               "five blocks per CU: five times 32 KB, all of a CU's LDS, are not admitted");
 
 #ifdef RT_STAMPS
@@ -220,7 +238,7 @@ __device__ unsigned long long g_tstamps[24];
 
 // k_trace — see the head of this file.  Grid: any number of 256-thread blocks;
 // wave w of the grid owns stack[w * stack_cap ...] and hits[w * hit_cap ...].
-__global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
+__global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(SceneDev sc, TraceArgs t) {
   const int lane = threadIdx.x & 63;
   // The block starts on segment (block % QUEUE_SEGMENTS) of the frame's queue and
   // moves on to the other segments when that one is used up (any wave may take
@@ -252,9 +270,9 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
   // the lower index wins), and a scattered read per accepted hit is saved
   int slot_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
-  __shared__ uint32_t lds_words[(LDS_STACK_ROWS + TRACE_PARK_ROWS) * 256];
+  __shared__ uint32_t lds_words[(TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 256];
   uint32_t *const stack_l = lds_words + threadIdx.x; // stack_l[k * 256]: k-th stacked node
-  uint32_t *const park = stack_l + LDS_STACK_ROWS * 256; // park[k * 256]: k-th parked leaf
+  uint32_t *const park = stack_l + TRACE_STACK_ROWS * 256; // park[k * 256]: k-th parked leaf
   int sp = 0, node = 0;
   int n_park = 0;
   uint32_t n_rays = 0;
@@ -359,13 +377,42 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
       RT_TCOUNT(3, t_s2 - t_s1);
       // ---- shade the waiting hits, 64 at a time (the last few when nothing else is left) ----
       if (n_hits >= 64 || (n_hits > 0 && sp_w == 0 && drained)) {
-        // walks in progress step aside: their state goes to the wave's save area
-        save[0 * 64] = qa;
-        save[1 * 64] = qb;
-        save[2 * 64] = make_float4(len_s, bound, __int_as_float(slot_s), sPx);
-        save[3 * 64] = make_float4(sPy, sPz, __int_as_float(sp), __int_as_float(node));
-        save[4 * 64] = make_float4(__int_as_float(n_park | (state << 8) | ((int)shadow << 16)),
-                                   __uint_as_float(n_rays), 0.f, 0.f);
+        // Walks in progress step aside.  At this point a lane's parking rows are
+        // empty (worked off above) and so are the rows of its column above its stack
+        // of nodes: rows sp .. LDS_STACK_ROWS + TRACE_PARK_ROWS - 1, one stretch of
+        // the column.  The walk state, sixteen words, goes into the first sixteen of
+        // them, and the stack height itself, with the lane's state, into the last row
+        // of the column.  Through device memory (five float4 per lane out and back
+        // around every batch) the saved walks were a third of the kernel's traffic.
+        // A lane whose stack leaves fewer than seventeen rows (trees near the depth
+        // limit) sends the whole wave through the save area in device memory.
+        const bool save_in_lds = !__any(state == BUSY && sp > TRACE_SAVE_MAX_SP);
+        if (save_in_lds) {
+          uint32_t *const sv = stack_l + sp * 256;
+          sv[0 * 256] = __float_as_uint(qa.x);
+          sv[1 * 256] = __float_as_uint(qa.y);
+          sv[2 * 256] = __float_as_uint(qa.z);
+          sv[3 * 256] = __float_as_uint(qa.w);
+          sv[4 * 256] = __float_as_uint(qb.x);
+          sv[5 * 256] = __float_as_uint(qb.y);
+          sv[6 * 256] = __float_as_uint(qb.z);
+          sv[7 * 256] = __float_as_uint(qb.w);
+          sv[8 * 256] = __float_as_uint(len_s);
+          sv[9 * 256] = __float_as_uint(bound);
+          sv[10 * 256] = (uint32_t)slot_s;
+          sv[11 * 256] = __float_as_uint(sPx);
+          sv[12 * 256] = __float_as_uint(sPy);
+          sv[13 * 256] = __float_as_uint(sPz);
+          sv[14 * 256] = (uint32_t)node;
+          sv[15 * 256] = n_rays;
+          park[(TRACE_PARK_ROWS - 1) * 256] = (uint32_t)sp | ((uint32_t)state << 8);
+        } else {
+          save[0 * 64] = qa;
+          save[1 * 64] = qb;
+          save[2 * 64] = make_float4(len_s, bound, __int_as_float(slot_s), sPx);
+          save[3 * 64] = make_float4(sPy, sPz, __int_as_float(sp), __int_as_float(node));
+          save[4 * 64] = make_float4(__int_as_float(state << 8), __uint_as_float(n_rays), 0.f, 0.f);
+        }
         uint32_t shade_rays = 0;
         while (n_hits >= 64 || (n_hits > 0 && sp_w == 0 && drained)) {
           const uint32_t n = n_hits < 64 ? n_hits : 64;
@@ -379,7 +426,24 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
         // nothing computed before this point may be carried in registers past it:
         // the walk state below is what the loads return
         asm volatile("" ::: "memory");
-        {
+        if (save_in_lds) {
+          const uint32_t packed = park[(TRACE_PARK_ROWS - 1) * 256];
+          sp = (int)(packed & 0xffu);
+          state = (int)(packed >> 8);
+          const uint32_t *const sv = stack_l + sp * 256;
+          qa = make_float4(__uint_as_float(sv[0 * 256]), __uint_as_float(sv[1 * 256]),
+                           __uint_as_float(sv[2 * 256]), __uint_as_float(sv[3 * 256]));
+          qb = make_float4(__uint_as_float(sv[4 * 256]), __uint_as_float(sv[5 * 256]),
+                           __uint_as_float(sv[6 * 256]), __uint_as_float(sv[7 * 256]));
+          len_s = __uint_as_float(sv[8 * 256]);
+          bound = __uint_as_float(sv[9 * 256]);
+          slot_s = (int)sv[10 * 256];
+          sPx = __uint_as_float(sv[11 * 256]);
+          sPy = __uint_as_float(sv[12 * 256]);
+          sPz = __uint_as_float(sv[13 * 256]);
+          node = (int)sv[14 * 256];
+          n_rays = sv[15 * 256] + shade_rays;
+        } else {
           const float4 s2 = save[2 * 64], s3 = save[3 * 64], s5 = save[4 * 64];
           qa = save[0 * 64];
           qb = save[1 * 64];
@@ -391,11 +455,14 @@ __global__ __launch_bounds__(256, 5) void k_trace(SceneDev sc, TraceArgs t) {
           sPz = s3.y;
           sp = __float_as_int(s3.z);
           node = __float_as_int(s3.w);
-          const int packed = __float_as_int(s5.x);
-          n_park = packed & 0xff;
-          state = (packed >> 8) & 0xff;
-          shadow = ((packed >> 16) & 1) != 0;
+          state = (__float_as_int(s5.x) >> 8) & 0xff;
           n_rays = __float_as_uint(s5.y) + shade_rays;
+        }
+        {
+          n_park = 0; // worked off before the batch
+          // a walking lane's item says which kind it is (a lane without an item gets
+          // the flag with its next one)
+          shadow = (__float_as_uint(qa.w) & RT_ITEM_SHADOW) != 0;
           // per-ray constants of the walk, by the operations that made them at the fetch
           a = dot3(qb.x, qb.y, qb.z, qb.x, qb.y, qb.z);
           a4 = 4.0f * a;

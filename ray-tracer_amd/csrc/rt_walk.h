@@ -704,27 +704,28 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, ShadeArgs s) {
       for (int l = s.light_begin; l < s.light_end; l++) {
         float fColor[3] = {0, 0, 0};
         float lx = 0, ly = 0, lz = 0, angle = 0;
-        bool blocked = false;
-        if (lit) {
+        if (lit)
           angle = phong_light(sf, h, dx, dy, dz, sc.lights[l], fColor, lx, ly, lz);
-          // renderer.cpp:119: the shadow ray starts exactly at P; its triangles
-          // here, unless a hierarchy walk over the triangles follows
-          if (sc.tbvh == nullptr) {
-            float len_t = RT_INF, tx, ty, tz;
-            int idx_t = -1;
-            lane_triangles(sc, true, h.Px, h.Py, h.Pz, lx, ly, lz, len_t, idx_t, tx, ty, tz);
-            blocked = idx_t >= 0;
-            if (blocked)
-              n_rays++; // traced to the end here; the others are counted by the walk
-          }
-        }
         const uint32_t c0 = (uint32_t)((fColor[0] * angle) * wl),
                        c1 = (uint32_t)((fColor[1] * angle) * wl),
                        c2 = (uint32_t)((fColor[2] * angle) * wl);
         // the shadow item: tagA = pixel, tagB = the three integer contributions
         // (each <= 255), 10 bits apiece
         const uint32_t packed = (c0 & 0x3ffu) | ((c1 & 0x3ffu) << 10) | ((c2 & 0x3ffu) << 20);
-        queue_push_raw(s.shadow, lit && !blocked,
+        // a light that cannot add one unit to any channel casts no shadow ray
+        const bool cast = lit && packed != 0;
+        bool blocked = false;
+        // renderer.cpp:119: the shadow ray starts exactly at P; its triangles
+        // here, unless a hierarchy walk over the triangles follows
+        if (cast && sc.tbvh == nullptr) {
+          float len_t = RT_INF, tx, ty, tz;
+          int idx_t = -1;
+          lane_triangles(sc, true, h.Px, h.Py, h.Pz, lx, ly, lz, len_t, idx_t, tx, ty, tz);
+          blocked = idx_t >= 0;
+          if (blocked)
+            n_rays++; // traced to the end here; the others are counted by the walk
+        }
+        queue_push_raw(s.shadow, cast && !blocked,
                        make_float4(h.Px, h.Py, h.Pz, __uint_as_float(pixel)),
                        make_float4(lx, ly, lz, __uint_as_float(packed)));
       }

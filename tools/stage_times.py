@@ -1,7 +1,7 @@
 """Stage times of the bench frame, one frame at a time, for a given build of the
 library: stage_times.py [path/to/librt_amd.so] [workload] [frames]
 Prints the median and minimum over the frames of (primary, bounce levels, final
-sum) in ms.  tools/ab.sh runs it alternately for two builds on the same box."""
+sum) in ms and the CRC32 of the last frame (two builds must print the same).  tools/ab.sh runs it alternately for two builds on the same box."""
 import os
 import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,8 +27,10 @@ with rtamd.DeviceScene(sc) as ds:
     for _ in range(frames):
         ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth)
         t.append(ds.kernel_times())
+import zlib  # noqa: E402
+crc = zlib.crc32(fb.cpu().numpy().tobytes())
 t = np.array(t)
 med, mn = np.median(t, 0), t.min(0)
 print(f"{os.path.basename(os.path.dirname(rtamd.LIB_PATH))}/{os.path.basename(rtamd.LIB_PATH)}: "
       f"median primary {med[0]:.3f} bounce {med[1]:.3f} sum {med[2]:.3f} = {med.sum():.3f} ms; "
-      f"min {mn[0]:.3f} {mn[1]:.3f} {mn[2]:.3f} = {mn.sum():.3f} ms", flush=True)
+      f"min {mn[0]:.3f} {mn[1]:.3f} {mn[2]:.3f} = {mn.sum():.3f} ms; frame crc {crc:08x}", flush=True)
