@@ -80,6 +80,15 @@ constexpr size_t kMaxBouncePixels = (size_t)1 << 26;
 constexpr size_t kSmallSharePixels = 1500000; // see bounce_needs
 constexpr size_t kCheckPinnedRays = 256;      // see gpu_check_intersection
 
+// Measurement knob of the one-launch bounce kernel, read once from the environment
+// (tools/ only; the default is what ships): RT_AMD_TRACE_SMALL_GRID = percent of the
+// resident grid that a small share of a frame runs on (bounce_needs).
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+static const int g_trace_small_grid_pct = env_int("RT_AMD_TRACE_SMALL_GRID", 50);
+
 // What the bounce levels of one frame need besides the scene: ray queues, hit
 // lists, shadow items, control words and the per-pixel integer sums.  All of it
 // is carved out of ONE region of device memory, so that the same launch code
@@ -508,7 +517,7 @@ BounceNeeds bounce_needs(const rt_scene *S, int max_depth, size_t frame_pixels,
     // four frames in flight 1.12 -> 1.02 ms; a whole frame on half the grid loses).
     int blocks = S->trace_blocks;
     if (owned_pixels < kSmallSharePixels && blocks >= 128)
-      blocks /= 2;
+      blocks = blocks * g_trace_small_grid_pct / 100;
     n.trace_waves = (size_t)blocks * 4;
     if (max_bytes) {
       BounceArena probe;

@@ -752,6 +752,19 @@ extern "C" int rt_debug_trace_stamps(unsigned long long *out24) {
     return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_tstamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
+// Reads and clears the service-phase timeline of the sampled waves of k_trace
+// (rt_trace.h, g_tlog): TLOG_WAVES x TLOG_RECS x 4 words.
+extern "C" int rt_debug_trace_log(uint32_t *out, int *n_waves, int *n_recs) {
+  *n_waves = TLOG_WAVES;
+  *n_recs = TLOG_RECS;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tlog), sizeof(uint32_t) * TLOG_WAVES * TLOG_RECS * 4) !=
+      hipSuccess)
+    return -1;
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tlog)) != hipSuccess)
+    return -1;
+  return hipMemset(p, 0, sizeof(uint32_t) * TLOG_WAVES * TLOG_RECS * 4) == hipSuccess ? 0 : -1;
+}
 #endif
 
 hipError_t launch_sum_rays(uint64_t *parts, uint64_t *total, hipStream_t st) {

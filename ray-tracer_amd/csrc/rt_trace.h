@@ -229,6 +229,11 @@ static_assert((TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 1024 < 32768,
 // end time of the last wave and [18] the sum of the waves' end times, both in
 // cycles after the first wave's start ([19])
 __device__ unsigned long long g_tstamps[24];
+// A timeline of every TLOG_EVERY-th wave (tools/trace_timeline.py): one record per
+// service phase, {cycles since the wave started / 16, lanes walking at entry, items on
+// the wave's stack, hits waiting | drained << 16 | visits since the last phase << 20}
+constexpr int TLOG_WAVES = 32, TLOG_RECS = 1024, TLOG_EVERY = 160;
+__device__ uint32_t g_tlog[TLOG_WAVES][TLOG_RECS][4];
 #define RT_TSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define RT_TCOUNT(k, v) tst[k] += (v)
 #else
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(SceneDev sc, Trac
 #ifdef RT_STAMPS
   unsigned long long tst[24] = {};
   float dbg_near = 0.f;
+  unsigned long long tlog_visits = 0;
 #endif
   RT_TSTAMP(t_begin);
 
@@ -291,6 +297,17 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(SceneDev sc, Trac
         __any(state == BUSY && n_park > TRACE_PARK_FULL)) {
       RT_TSTAMP(t_s0);
       RT_TCOUNT(7, 1);
+#ifdef RT_STAMPS
+      if (wave_id % TLOG_EVERY == 0 && wave_id / TLOG_EVERY < TLOG_WAVES && tst[7] <= TLOG_RECS &&
+          lane == 0) {
+        uint32_t *r = g_tlog[wave_id / TLOG_EVERY][tst[7] - 1];
+        r[0] = (uint32_t)((t_s0 - t_begin) >> 4);
+        r[1] = 64u - (uint32_t)n_free;
+        r[2] = sp_w;
+        r[3] = n_hits | ((drained ? 1u : 0u) << 16) | ((uint32_t)(tst[6] - tlog_visits) << 20);
+      }
+      tlog_visits = tst[6];
+#endif
       RT_TCOUNT(13, (n_free == 64 || (more && n_free >= t.fetch_at)) ? 0 : 1);
       // ---- work off parked leaves, all lanes together: the cheap screen on every
       // parked leaf first, then the full test only as often as the busiest lane

@@ -108,10 +108,13 @@ for st in ("primary", "bounce", "compose"):
     # reads high on short dispatches, so it is capped at the maximum clock)
     clock = min(2.4, gui / (ms * 1e-3) / 1e9) if ms > 0 and gui > 0 else 2.4
     hbm = (v.get("FETCH_SIZE", 0.0) * 2 + v.get("WRITE_SIZE", 0.0)) * 1024
-    # mean resident waves per SIMD over the stage: wave-cycles (the counter ticks once
-    # per four cycles) over the cycles of the launch on the chip's 1024 SIMDs; and
-    # the same over the cycles in which a shader engine had any wave at all
-    occ = v.get("SQ_WAVE_CYCLES", 0.0) * 4 / max(1.0, ms * 1e-3 * clock * 1e9 * 1024)
+    # mean resident waves per SIMD over the stage: wave-cycles over the cycles of the
+    # launch on the chip's 1024 SIMDs.  As rocprofv3 sums it over the chip the counter
+    # advances once per TWO cycles of a resident wave: calibrated on k_trace, whose
+    # 5 120 waves (5 per SIMD, the launch bound) are resident for nearly the whole
+    # launch and read 9.1 with a factor of 4; k_render (bound 4 per SIMD) and k_compose
+    # (8) read 4.07 and 6.3 with 2
+    occ = v.get("SQ_WAVE_CYCLES", 0.0) * 2 / max(1.0, ms * 1e-3 * clock * 1e9 * 1024)
     lds_active = v.get("SQ_LDS_IDX_ACTIVE", 0.0)
     lds_conflict = v.get("SQ_LDS_BANK_CONFLICT", 0.0)
     e = {
