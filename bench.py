@@ -343,7 +343,13 @@ def main():
         }
         if in_flight is not None:
             out["frames_in_flight_4"] = in_flight
-        out["roofline"] = roofline(name, args, world, stage_ms, my_rays_per_frame, n_tests_per_ray)
+        # framebuffer bytes written per stage: this rank's rows x 4 bytes by the primary
+        # pass and again by the final sum (which only runs when the frame has bounces)
+        owned_rows = sum(min(band_rows, h - r0) for r0 in range(rank * band_rows, h, world * band_rows))
+        fb_px = owned_rows * w * 4
+        fb_bytes = [fb_px, 0, fb_px if stage_ms[2] > 0 else 0]
+        out["roofline"] = roofline(name, args, world, stage_ms, my_rays_per_frame, n_tests_per_ray,
+                                   fb_bytes)
         if world == 1 and args.screen != "off" and not args.no_plain_loop:
             if sc.t_size + sc.s_size > PLAIN_LOOP_MAX_PRIMS:
                 out["roofline"]["plain_loop"] = None   # minutes per frame at this size: not run
@@ -400,7 +406,7 @@ def profiled_counters(workload):
         return None
 
 
-def roofline(name, args, world, stage_ms, rays_per_frame, flop_per_ray):
+def roofline(name, args, world, stage_ms, rays_per_frame, flop_per_ray, fb_bytes=None):
     """Where the kernels of one frame sit against the vector-FP32 ceiling.
 
     achieved = executed vector lane-operations per second of the stage that takes
@@ -433,7 +439,20 @@ def roofline(name, args, world, stage_ms, rays_per_frame, flop_per_ray):
                                    (1024 * c["clock_ghz"] * 1e9 * stage_ms[k] * 1e-3),
                 "hbm_bytes": c["hbm_bytes"],
                 "hbm_gbs": c["hbm_bytes"] / (stage_ms[k] * 1e-3) / 1e9,
+                # of the wave-cycles of the stage: parked at a wait (memory, LDS), and
+                # the mean number of waves resident per SIMD
+                "waves_parked_frac": c.get("wait_any_frac"),
+                "occupancy_waves_per_simd": c.get("occupancy_waves_per_simd"),
+                # cycles the LDS spent on bank conflicts over its active cycles
+                # (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE): the walks' stacks are laid
+                # out word (row x 256 + thread) so that this is zero
+                "lds_bank_conflict_frac": c.get("lds_bank_conflict_frac"),
             })
+        if fb_bytes and fb_bytes[k] and stage_ms[k] > 0:
+            # the framebuffer bytes the stage writes (4 per pixel: the primary pass
+            # writes every pixel, the final sum rewrites them), as a rate
+            e["fb_write_bytes"] = fb_bytes[k]
+            e["fb_write_gbs"] = fb_bytes[k] / (stage_ms[k] * 1e-3) / 1e9
         stages[st] = e
     dom = max(STAGES, key=lambda st: stages[st]["ms"])
     d = stages[dom]

@@ -372,12 +372,20 @@ int rt_band_plan(int h, int band_rows, int band_index, int band_count,
  * in time on one GPU race, also from different scenes or streams; the caller
  * serialises them.  rt_scene_queue_overflowed does not see this variant's
  * frames: pass dev_overflow (device uint32, or NULL), which the frame sets to
- * 0 or 1.                                                                     */
+ * 0 or 1.
+ * Under stream capture: the FIRST call on a device (it asks the runtime for the
+ * array's address, which loads the code object) and the first call after the
+ * camera's origin changed (it rebuilds the scene's eye-relative records and
+ * waits on events of earlier frames) must have run outside the capture; later
+ * calls only enqueue kernels, memsets and one device-to-device copy of four
+ * bytes on frame->stream.                                                    */
 #define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
 int rt_render_device_noalloc(rt_scene *scene, const camera *cam,
                              const rt_frame *frame, uint64_t *dev_ray_count,
                              uint32_t *dev_overflow);
-/* Bytes of that array the frame would use (0 = no bounce machinery needed).  */
+/* Bytes of that array the frame would use (0 = no bounce machinery needed).
+ * Only frame->w, h, max_depth, flags and the band fields are read; dev_fb may
+ * be NULL here.                                                              */
 int rt_noalloc_scratch_needed(rt_scene *scene, const rt_frame *frame,
                               uint64_t *bytes);
 

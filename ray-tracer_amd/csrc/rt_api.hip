@@ -994,7 +994,12 @@ int rt_noalloc_scratch_needed(rt_scene *S, const rt_frame *fr, uint64_t *bytes) 
   camera cam;
   rt_camera_default(&cam);
   FramePlan P;
-  int rc = plan_frame(S, &cam, fr, P);
+  if (!fr)
+    return fail(RT_ERR_BAD_ARG, "frame is NULL");
+  rt_frame sized = *fr; // only the sizes matter here: no framebuffer needed
+  if (!sized.dev_fb)
+    sized.dev_fb = reinterpret_cast<uint8_t *>(uintptr_t(256));
+  int rc = plan_frame(S, &cam, &sized, P);
   if (rc)
     return rc;
   if (P.bounces) {

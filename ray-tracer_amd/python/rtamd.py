@@ -404,7 +404,7 @@ class DeviceScene:
                                               dev_ray_count, dev_overflow))
 
     def noalloc_scratch_needed(self, w: int, h: int, max_depth: int) -> int:
-        f = Frame(1, None, w, h, max_depth, 8, 0, 1, 0, None)
+        f = Frame(None, None, w, h, max_depth, 8, 0, 1, 0, None)   # sizes only: no framebuffer
         n = C.c_uint64(0)
         _check(lib().rt_noalloc_scratch_needed(self.handle, C.byref(f), C.byref(n)))
         return int(n.value)

@@ -359,3 +359,26 @@ def test_frames_repeat_bit_for_bit_in_both_bounce_modes():
                     if first is None:
                         first = (f, i, n)
                     assert n == first[2] and torch.equal(i, first[1]) and torch.equal(f, first[0]), one
+
+
+def test_million_triangle_1080p_frame_repeats_16_times_per_mode():
+    """The frame on which walks in progress are shared between lanes the most: the
+    1 M-triangle height field + 10 000 spheres at 1920x1080, depth 8.  Once a launch's
+    queue is used up, idle lanes take over parts of other lanes' walks, and which lane
+    helps whom differs from run to run (rt_walk.h); the order-free nearest-hit rule
+    (renderer.cpp:159,170,181) must make that invisible.  Sixteen frames with the shadow
+    walks on the scene's side stream and sixteen with every launch on one stream:
+    identical bytes, ids and ray counts."""
+    import torch
+    sc = rtamd.mesh_scene(1000, 500, grid=100)
+    with rtamd.DeviceScene(sc) as ds:
+        first = None
+        for side in (1, 0):
+            ds.set_side_stream(side)
+            for k in range(16):
+                f, i, n = _device_frame(ds, 1920, 1080, 8, "auto")
+                if first is None:
+                    first = (f, i, n)
+                assert n == first[2], (side, k)
+                assert torch.equal(i, first[1]), (side, k)
+                assert torch.equal(f, first[0]), (side, k)
