@@ -332,6 +332,11 @@ def main():
                        "spheres": sc.s_size, "triangles": sc.t_size, "lights": sc.l_size,
                        "materials": sc.mat_sphere is not None,
                        "rays_per_frame": total_rays // args.steps,
+                       # device-counted, i.e. the rays actually traced: a bounce hit casts
+                       # no shadow ray towards a light whose contribution truncates to zero
+                       # in every channel (same image, fewer rays than counting one shadow
+                       # ray per light and hit would give)
+                       "rays_counted": "traced",
                        "sharding": f"row bands of {band_rows}, round-robin over {world} GPU(s)",
                        "screen": args.screen, "frames_in_flight": n_buf,
                        "one_launch": args.one_launch},
