@@ -803,7 +803,7 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
     ta.overflow = A->overflow_flag();
     ta.max_depth = fr->max_depth;
     ta.fetch_at = rt::WALK_FETCH_AT;
-    HIP_TRY(rt::launch_trace(sd, ta, P.trace_blocks, st)); // <= A->have.trace_waves / 4
+    HIP_TRY(rt::launch_trace(sd, ta, S->bvh_depth, P.trace_blocks, st)); // <= A->have.trace_waves / 4
     if (S->timing)
       HIP_TRY(hipEventRecord(S->ev_t[2], st));
     HIP_TRY(rt::launch_compose(fr->dev_fb, A->extra, fr->w, fr->h, P.band_rows,

@@ -148,7 +148,9 @@ hipError_t launch_bounce(const SceneDev &sc, const BounceDev &bd, bool beam,
                          int blocks, hipStream_t st);
 hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, bool triangles,
                        int blocks, hipStream_t st);
-hipError_t launch_trace(const SceneDev &sc, const TraceArgs &t, int blocks, hipStream_t st);
+// bvh_depth: levels of inner nodes of the scene's sphere tree (<= LDS_WALK_MAX_DEPTH)
+hipError_t launch_trace(const SceneDev &sc, const TraceArgs &t, int bvh_depth, int blocks,
+                        hipStream_t st);
 // Blocks of k_trace that can be resident at once on the current device (what a
 // launch should use: a block that waits for a free slot finds nothing left to do).
 int trace_resident_blocks();

@@ -702,17 +702,26 @@ hipError_t launch_walk(const SceneDev &sc, const WalkArgs &w, bool any_hit, bool
   return hipGetLastError();
 }
 
-hipError_t launch_trace(const SceneDev &sc, const TraceArgs &t, int blocks, hipStream_t st) {
-  if (sc.bvh == nullptr || sc.tbvh != nullptr || blocks <= 0)
+hipError_t launch_trace(const SceneDev &sc, const TraceArgs &t, int bvh_depth, int blocks,
+                        hipStream_t st) {
+  if (sc.bvh == nullptr || sc.tbvh != nullptr || blocks <= 0 || bvh_depth < 1 ||
+      bvh_depth > LDS_WALK_MAX_DEPTH)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_trace, dim3(blocks), dim3(256), 0, st, sc, t);
+  // the fewest stack rows that serve the tree: the rest of the column parks leaves
+  if (bvh_depth <= 6)
+    hipLaunchKernelGGL(k_trace<trace_stack_rows(6)>, dim3(blocks), dim3(256), 0, st, sc, t);
+  else if (bvh_depth == 7)
+    hipLaunchKernelGGL(k_trace<trace_stack_rows(7)>, dim3(blocks), dim3(256), 0, st, sc, t);
+  else
+    hipLaunchKernelGGL(k_trace<trace_stack_rows(8)>, dim3(blocks), dim3(256), 0, st, sc, t);
   return hipGetLastError();
 }
 
 int trace_resident_blocks() {
   int dev = 0, per_cu = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace, 256, 0) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<LDS_STACK_ROWS>, 256, 0) !=
+          hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
       per_cu <= 0 || cus <= 0)
     return 1024;

@@ -202,19 +202,20 @@ __device__ __forceinline__ ShadeResult trace_shade(const SceneDev &sc, float4 *s
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 5
 #endif
-#ifndef RT_TRACE_STACK_ROWS
-#define RT_TRACE_STACK_ROWS LDS_STACK_ROWS
-#endif
-#ifndef RT_TRACE_PARK_ROWS
-#define RT_TRACE_PARK_ROWS 9
-#endif
-constexpr int TRACE_STACK_ROWS = RT_TRACE_STACK_ROWS;
-constexpr int TRACE_PARK_ROWS = RT_TRACE_PARK_ROWS;
-constexpr int TRACE_PARK_FULL = TRACE_PARK_ROWS - BVH_WIDTH;
+// The column has TRACE_ROWS rows in all.  How many of them the stack needs depends on
+// the scene's tree (three per level of inner nodes but the last, and the row of the
+// stores that do not count), and every row it does not need is one more parked leaf
+// before a lane forces a work-off: the kernel exists for stacks of 22, 19 and 16 rows
+// (trees of 8, 7 and at most 6 levels), and launch_trace picks by the tree's depth.
+// The bench scene's tree has 7 levels: 12 parking rows instead of 9 took its bounce
+// stage from 3.91 to 3.83 ms.
+constexpr int TRACE_ROWS = 31;
+constexpr int trace_stack_rows(int depth) { return 3 * (depth - 1) + 1; }
+static_assert(trace_stack_rows(LDS_WALK_MAX_DEPTH) == LDS_STACK_ROWS, "the deepest admitted tree");
 // A walk steps aside for a batch of shading into its own column (k_trace): sixteen
 // rows from its stack height on, and the column's last row.
-constexpr int TRACE_SAVE_MAX_SP = TRACE_STACK_ROWS + TRACE_PARK_ROWS - 1 - 16;
-static_assert((TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 1024 < 32768,
+constexpr int TRACE_SAVE_MAX_SP = TRACE_ROWS - 1 - 16;
+static_assert(TRACE_ROWS * 1024 < 32768,
               "five blocks per CU: five times 32 KB, all of a CU's LDS, are not admitted");
 
 #ifdef RT_STAMPS
@@ -243,7 +244,12 @@ __device__ uint32_t g_tlog[TLOG_WAVES][TLOG_RECS][4];
 
 // k_trace — see the head of this file.  Grid: any number of 256-thread blocks;
 // wave w of the grid owns stack[w * stack_cap ...] and hits[w * hit_cap ...].
+// TRACE_STACK_ROWS: rows of a lane's column that hold its stack of nodes (the scene's
+// tree must not be deeper than they serve); the others hold its parked leaves.
+template <int TRACE_STACK_ROWS>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(SceneDev sc, TraceArgs t) {
+  constexpr int TRACE_PARK_ROWS = TRACE_ROWS - TRACE_STACK_ROWS;
+  constexpr int TRACE_PARK_FULL = TRACE_PARK_ROWS - BVH_WIDTH;
   const int lane = threadIdx.x & 63;
   // The block starts on segment (block % QUEUE_SEGMENTS) of the frame's queue and
   // moves on to the other segments when that one is used up (any wave may take
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(SceneDev sc, Trac
   // the lower index wins), and a scattered read per accepted hit is saved
   int slot_s = -1;
   float sPx = 0, sPy = 0, sPz = 0;
-  __shared__ uint32_t lds_words[(TRACE_STACK_ROWS + TRACE_PARK_ROWS) * 256];
+  __shared__ uint32_t lds_words[TRACE_ROWS * 256];
   uint32_t *const stack_l = lds_words + threadIdx.x; // stack_l[k * 256]: k-th stacked node
   uint32_t *const park = stack_l + TRACE_STACK_ROWS * 256; // park[k * 256]: k-th parked leaf
   int sp = 0, node = 0;
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(SceneDev sc, Trac
       if (n_hits >= 64 || (n_hits > 0 && sp_w == 0 && drained)) {
         // Walks in progress step aside.  At this point a lane's parking rows are
         // empty (worked off above) and so are the rows of its column above its stack
-        // of nodes: rows sp .. LDS_STACK_ROWS + TRACE_PARK_ROWS - 1, one stretch of
+        // of nodes: rows sp .. TRACE_ROWS - 1, one stretch of
         // the column.  The walk state, sixteen words, goes into the first sixteen of
         // them, and the stack height itself, with the lane's state, into the last row
         // of the column.  Through device memory (five float4 per lane out and back
