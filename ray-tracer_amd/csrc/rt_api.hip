@@ -80,14 +80,16 @@ constexpr size_t kMaxBouncePixels = (size_t)1 << 26;
 constexpr size_t kSmallSharePixels = 1500000; // see bounce_needs
 constexpr size_t kCheckPinnedRays = 256;      // see gpu_check_intersection
 
-// Measurement knob of the one-launch bounce kernel, read once from the environment
-// (tools/ only; the default is what ships): RT_AMD_TRACE_SMALL_GRID = percent of the
+// Measurement knobs of the one-launch bounce kernel, read once from the environment
+// (tools/ only; the defaults are what ships): RT_AMD_TRACE_SMALL_GRID = percent of the
 // resident grid that a small share of a frame runs on (bounce_needs).
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
 static const int g_trace_small_grid_pct = env_int("RT_AMD_TRACE_SMALL_GRID", 50);
+// RT_AMD_TRACE_FETCH_AT = idle lanes at which a wave of that kernel stops to refill
+static const int g_trace_fetch_at = env_int("RT_AMD_TRACE_FETCH_AT", rt::TRACE_FETCH_AT);
 
 // What the bounce levels of one frame need besides the scene: ray queues, hit
 // lists, shadow items, control words and the per-pixel integer sums.  All of it
@@ -802,7 +804,7 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
     ta.ray_count = dev_ray_count;
     ta.overflow = A->overflow_flag();
     ta.max_depth = fr->max_depth;
-    ta.fetch_at = rt::WALK_FETCH_AT;
+    ta.fetch_at = g_trace_fetch_at;
     HIP_TRY(rt::launch_trace(sd, ta, S->bvh_depth, P.trace_blocks, st)); // <= A->have.trace_waves / 4
     if (S->timing)
       HIP_TRY(hipEventRecord(S->ev_t[2], st));

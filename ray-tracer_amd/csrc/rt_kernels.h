@@ -105,6 +105,12 @@ struct TraceArgs {
   int max_depth;
   int fetch_at;       // refill a wave when this many of its lanes have nothing to do
 };
+// Refill threshold of k_trace.  With nine parking rows 24 and 40 were level (4.94 and
+// 4.97 ms on the bench frame then); with twelve (rt_trace.h: the rows a 7-level tree's
+// stack leaves free) a lane holds more touched leaves before it forces a work-off, and
+// longer stretches of visits between service phases pay: 16 / 24 / 32 / 40 / 48 / 56
+// idle lanes give 3.96 / 3.84 / 3.80 / 3.75 / 3.76 / 3.84 ms.
+constexpr int TRACE_FETCH_AT = 40;
 constexpr uint32_t TRACE_SAVE_WORDS = 20;
 constexpr uint32_t TRACE_HIT_CAP = 128; // < 64 waiting + <= 64 handed in at once
 
