@@ -90,6 +90,9 @@ static int env_int(const char *name, int dflt) {
 static const int g_trace_small_grid_pct = env_int("RT_AMD_TRACE_SMALL_GRID", 50);
 // RT_AMD_TRACE_FETCH_AT = idle lanes at which a wave of that kernel stops to refill
 static const int g_trace_fetch_at = env_int("RT_AMD_TRACE_FETCH_AT", rt::TRACE_FETCH_AT);
+// the same for the launch-per-level walks: nearest-hit and shadow walks
+static const int g_walk_fetch_at = env_int("RT_AMD_WALK_FETCH_AT", rt::WALK_FETCH_AT);
+static const int g_walk_fetch_at_shadow = env_int("RT_AMD_WALK_FETCH_AT_SHADOW", rt::WALK_FETCH_AT);
 
 // What the bounce levels of one frame need besides the scene: ray queues, hit
 // lists, shadow items, control words and the per-pixel integer sums.  All of it
@@ -834,7 +837,7 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
     tl.idx = tri_walks ? A->tri_hit_idx : nullptr;
     rt::WalkArgs wa;
     memset(&wa, 0, sizeof wa);
-    wa.fetch_at = rt::WALK_FETCH_AT;
+    wa.fetch_at = g_walk_fetch_at;
     wa.in = bd.in;
     wa.extra = A->extra;
     // Each ray is counted once, by the first walk it goes through.  The sphere
@@ -885,7 +888,7 @@ static int render_frame_launches(rt_scene *S, const BounceArena *A, hipStream_t 
         }
         rt::WalkArgs ws;
         memset(&ws, 0, sizeof ws);
-        ws.fetch_at = rt::WALK_FETCH_AT;
+        ws.fetch_at = g_walk_fetch_at_shadow;
         ws.in = sa.shadow;
         ws.extra = A->extra;
         // spheres first (the cheaper walk); only what they leave unoccluded is
