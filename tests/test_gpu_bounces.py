@@ -382,3 +382,25 @@ def test_million_triangle_1080p_frame_repeats_16_times_per_mode():
                 assert n == first[2], (side, k)
                 assert torch.equal(i, first[1]), (side, k)
                 assert torch.equal(f, first[0]), (side, k)
+
+
+@pytest.mark.parametrize("grid,levels", [(150, 8), (100, 7), (60, 6), (12, 4)])
+def test_one_launch_kernel_for_every_depth_of_tree(oracle, grid, levels):
+    """The one-launch kernel exists per depth of the sphere tree (a lane's LDS column is
+    split between its stack of nodes and its parked leaves by what the tree needs:
+    rt_trace.h): grids whose trees have 8, 7, 6 and 4 levels of inner nodes, all bounce
+    levels in one launch against the launch-per-level path on the whole frame and
+    against the oracle on every 16th row."""
+    import torch
+    sc = rtamd.material_grid_scene(grid, grid)
+    w, h, depth = 960, 544, 5
+    with rtamd.DeviceScene(sc) as ds:
+        d = ds.describe()
+        assert d["sphere_levels"] == levels and d["lds_stacks"] and d["one_launch"]
+        f1, i1, n1 = _device_frame(ds, w, h, depth, "auto")
+        ds.set_one_launch(0)
+        f0, i0, n0 = _device_frame(ds, w, h, depth, "auto")
+        assert n0 == n1 and torch.equal(i0, i1) and torch.equal(f0, f1)
+    fo, io, _ = oracle.render(sc, w, h, max_depth=depth, rows=(0, h, 16))
+    assert np.array_equal(i1.cpu().numpy()[::16], io[::16])
+    assert np.array_equal(f1.cpu().numpy()[::16], fo[::16])
