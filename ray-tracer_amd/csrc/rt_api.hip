@@ -88,6 +88,8 @@ static int env_int(const char *name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 static const int g_trace_small_grid_pct = env_int("RT_AMD_TRACE_SMALL_GRID", 50);
+// RT_AMD_TRACE_SMALL_PIXELS = owned pixels below which a share counts as small
+static const int g_trace_small_pixels = env_int("RT_AMD_TRACE_SMALL_PIXELS", (int)kSmallSharePixels);
 // RT_AMD_TRACE_FETCH_AT = idle lanes at which a wave of that kernel stops to refill
 static const int g_trace_fetch_at = env_int("RT_AMD_TRACE_FETCH_AT", rt::TRACE_FETCH_AT);
 // the same for the launch-per-level walks: nearest-hit and shadow walks
@@ -521,7 +523,7 @@ BounceNeeds bounce_needs(const rt_scene *S, int max_depth, size_t frame_pixels,
     // the other half of the chip is free for the frames beside it (1/8 share with
     // four frames in flight 1.12 -> 1.02 ms; a whole frame on half the grid loses).
     int blocks = S->trace_blocks;
-    if (owned_pixels < kSmallSharePixels && blocks >= 128)
+    if (owned_pixels < (size_t)g_trace_small_pixels && blocks >= 128)
       blocks = blocks * g_trace_small_grid_pct / 100;
     n.trace_waves = (size_t)blocks * 4;
     if (max_bytes) {
