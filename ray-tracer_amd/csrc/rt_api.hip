@@ -1192,6 +1192,7 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
       };
       std::vector<Item> todo;
       todo.push_back(Item{0, {}});
+      size_t levels = 0;
       while (!todo.empty()) {
         Item it = todo.back();
         todo.pop_back();
@@ -1202,6 +1203,7 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
             continue;
           auto boxes = it.boxes;
           boxes.push_back(rt::bvh_child_box(N, c));
+          levels = std::max(levels, boxes.size());
           if (link >= 0) {
             todo.push_back(Item{link, boxes});
             continue;
@@ -1228,6 +1230,11 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
       for (int i = 0; i < s->s_size; i++)
         if (seen[i] != 1)
           out[3]++; // sphere missing or duplicated
+      size_t least = 1; // levels of the shallowest four-way tree over s_size leaves
+      for (long reach = rt::BVH_WIDTH; reach < s->s_size; reach *= rt::BVH_WIDTH)
+        least++;
+      if (levels != least || (int)levels != H.depth)
+        out[3]++; // deeper than the walks' stacks are sized for, or misreported
     }
   }
   // ---- triangles: spheres + normal cones ----

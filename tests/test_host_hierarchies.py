@@ -38,7 +38,34 @@ def test_grids_and_mixed_scenes():
         assert_sound(o)
         assert o[0] > 0
     o = check(rtamd.grid_scene(100, 100))
-    assert o[0] == 5461      # 4^0 + ... + 4^6 nodes over 10 000 single-sphere leaves
+    # 10 000 single-sphere leaves: at least ceil(10 000 / 4) + ... + 1 = 3 334 nodes; two rounds of
+    # halving per node make 4^0 + ... + 4^6 = 5 461, the cuts by box area fewer
+    assert 3334 <= o[0] < 5461
+
+
+def test_sphere_tree_is_as_shallow_as_four_way_allows():
+    """The checker counts a tree that is deeper than ceil(log4 n) levels into out[3]: sizes around
+    the powers of four, clustered and coincident centres (cuts by area alone would make chains)."""
+    rng = np.random.RandomState(5)
+    for n in (1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 1024, 1025, 4096, 4097):
+        for kind in range(4):
+            if kind == 0:      # uniform cloud
+                c = rng.uniform(-50, 50, (n, 3))
+            elif kind == 1:    # a few tight clusters and far outliers
+                c = rng.normal(size=(n, 3)) * 0.01 + rng.randint(0, 3, (n, 1)) * 1000.0
+                c[:: max(1, n // 7)] += 1e6
+            elif kind == 2:    # all centres equal
+                c = np.zeros((n, 3))
+            else:              # a line with growing gaps
+                c = np.zeros((n, 3))
+                c[:, 0] = np.cumsum(np.arange(n, dtype=np.float64) ** 2)
+            c = c.astype(np.float32) + np.float32([0, 0, -80])
+            rad = rng.uniform(0.1, 2.0, n).astype(np.float32)
+            sc = rtamd.Scene(np.zeros((0, 9), np.float32), np.zeros((0, 3), np.uint8), c, rad,
+                             np.full((n, 3), 200, np.uint8), np.float32([[0, 50, 0]]))
+            o = check(sc)
+            assert_sound(o)
+            assert o[0] >= 1
 
 
 @pytest.mark.parametrize("rough", [0.0, 1.5, 6.0])
