@@ -296,8 +296,8 @@ int rt_render_device_selfcheck(rt_scene *scene, const camera *cam,
  * sphere and the triangle hierarchy for the scene and counts violated
  * invariants.  out (8 x int64): [0] sphere nodes (-1: no hierarchy), [1] spheres
  * sticking out of an ancestor box, [2] distance bounds above the true distance,
- * [3] primitives missing from or duplicated in a hierarchy, plus 1 if the
- * sphere hierarchy is not exactly ceil(log4 s_size) levels deep, [4] triangle nodes
+ * [3] primitives missing from or duplicated in a hierarchy, plus 1 for each
+ * hierarchy that is not exactly ceil(log4 leaves) levels deep, [4] triangle nodes
  * (-1: none), [5] triangles kept outside the hierarchy, [6] triangle corners
  * outside an ancestor sphere, [7] triangle normals outside an ancestor cone.
  * [1..3] and [6..7] must be 0.  No counterpart in the reference.             */

@@ -1253,6 +1253,8 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
       };
       std::vector<Item> todo;
       todo.push_back(Item{0, {}});
+      size_t levels = 0;
+      long in_tree = 0;
       while (!todo.empty()) {
         Item it = todo.back();
         todo.pop_back();
@@ -1263,11 +1265,13 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
             continue;
           auto bounds = it.bounds;
           bounds.push_back({N.s[c], N.ns[c]});
+          levels = std::max(levels, bounds.size());
           if (link >= 0) {
             todo.push_back(Item{link, bounds});
             continue;
           }
           const int idx = H.leaf_idx[(~link) >> 3];
+          in_tree++;
           seen[idx]++;
           const float *p = s->tris + 9 * (size_t)idx;
           // the triangle's unit normal, in double
@@ -1306,6 +1310,11 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
       for (int i = 0; i < s->t_size; i++)
         if (seen[i] > 1)
           out[3]++; // triangle in two places
+      size_t least = 1; // levels of the shallowest four-way tree over the leaves
+      for (long reach = rt::BVH_WIDTH; reach < in_tree; reach *= rt::BVH_WIDTH)
+        least++;
+      if (levels != least)
+        out[3]++; // deeper than the walks' stacks are sized for
     }
   }
   return RT_OK;

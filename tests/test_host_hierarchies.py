@@ -94,6 +94,27 @@ def test_awkward_triangles_stay_outside_the_tree():
     assert o[5] >= 25        # the slivers and the huge one are tested by every ray instead
 
 
+def test_triangle_tree_is_as_shallow_as_four_way_allows():
+    """Triangle soups whose cuts by size alone would make chains: coincident copies, a cluster with
+    far outliers, sizes around the powers of four."""
+    rng = np.random.RandomState(11)
+    one = np.float32([0, 0, -40, 3, 0, -40, 0, 5, -41])
+    for n in (1, 2, 4, 5, 16, 17, 64, 65, 257, 1025):
+        for kind in range(3):
+            if kind == 0:
+                t = np.tile(one, (n, 1))
+            elif kind == 1:
+                t = np.tile(one, (n, 1)) + np.tile(rng.normal(size=(n, 3)) * 0.05, (1, 3)).astype(np.float32)
+                t[:: max(1, n // 5)] += np.float32([1e4, 0, 0] * 3)
+            else:
+                t = (np.tile(one, (n, 1)) + np.tile(rng.uniform(-80, 80, (n, 3)), (1, 3))).astype(np.float32)
+            sc = rtamd.Scene(t.astype(np.float32), np.full((n, 3), 90, np.uint8), np.zeros((0, 3), np.float32),
+                             np.zeros(0, np.float32), np.zeros((0, 3), np.uint8), np.float32([[0, 50, 0]]))
+            o = check(sc)
+            assert_sound(o)
+            assert o[4] >= 1 and o[5] == 0, (n, kind, o)
+
+
 def test_random_scenes():
     for seed in range(300, 340):
         sc, _, _ = fuzz_parity.scene(seed)
