@@ -1325,7 +1325,7 @@ int rt_host_check_hierarchies(const scene_desc *s, int64_t *out) {
 // (per device) is kept and reused when the next call brings the same pointers,
 // sizes and bytes; two 64-bit hashes, one of the geometry and one of everything
 // else, decide the last point (a million triangles hash in a few ms, their
-// hierarchy takes 0.3 s to build).  The hashes are not cryptographic: they catch
+// hierarchy takes most of a second to build).  The hashes are not cryptographic: they catch
 // arrays edited in place between calls, not an adversary.  A host that never
 // edits its arrays in place can switch the hashing off (rt_cache_trust_pointers).
 } // extern "C"
