@@ -1,7 +1,8 @@
 """Stage times of the bench frame, one frame at a time, for a given build of the
 library: stage_times.py [path/to/librt_amd.so] [workload] [frames]
 Prints the median and minimum over the frames of (primary, bounce levels, final
-sum) in ms and the CRC32 of the last frame (two builds must print the same).  tools/ab.sh runs it alternately for two builds on the same box."""
+sum) in ms and the CRC32 of the last frame (two builds must print the same).  tools/ab.sh runs it alternately for two builds on the same box.
+SHARE=n in the environment: rank 0's bands of an n-way split (bands of 8 rows) instead of the whole frame."""
 import os
 import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,14 +19,16 @@ frames = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 sc, w, h, depth = bench.build_scene(name)
 dev = torch.device("cuda", 0)
 fb = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+share = int(os.environ.get("SHARE", "1"))
+kw = dict(max_depth=depth, band_rows=8, band_index=0, band_count=share)
 with rtamd.DeviceScene(sc) as ds:
     for _ in range(3):
-        ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth)
+        ds.render_device(fb.data_ptr(), None, w, h, **kw)
     torch.cuda.synchronize()
     ds.time_kernels(True)
     t = []
     for _ in range(frames):
-        ds.render_device(fb.data_ptr(), None, w, h, max_depth=depth)
+        ds.render_device(fb.data_ptr(), None, w, h, **kw)
         t.append(ds.kernel_times())
 import zlib  # noqa: E402
 crc = zlib.crc32(fb.cpu().numpy().tobytes())
