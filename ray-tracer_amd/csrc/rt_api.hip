@@ -79,6 +79,7 @@ constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
 constexpr size_t kMaxBouncePixels = (size_t)1 << 26;
 constexpr size_t kSmallSharePixels = 1500000; // see bounce_needs
 constexpr size_t kCheckPinnedRays = 256;      // see gpu_check_intersection
+constexpr int kBinMinSpheres = 64;            // scenes with fewer spheres get no lists by screen cell
 
 // Measurement knobs of the one-launch bounce kernel, read once from the environment
 // (tools/ only; the defaults are what ships): RT_AMD_TRACE_SMALL_GRID = percent of the
@@ -90,6 +91,9 @@ static int env_int(const char *name, int dflt) {
 static const int g_trace_small_grid_pct = env_int("RT_AMD_TRACE_SMALL_GRID", 50);
 // RT_AMD_TRACE_SMALL_PIXELS = owned pixels below which a share counts as small
 static const int g_trace_small_pixels = env_int("RT_AMD_TRACE_SMALL_PIXELS", (int)kSmallSharePixels);
+// RT_AMD_PRIMARY_BINS = 0: the rays from the eye walk the sphere hierarchy like all others
+// (measurement only; what ships lists the spheres by screen cell, k_bin_spheres).
+static const int g_primary_bins = env_int("RT_AMD_PRIMARY_BINS", 1);
 // RT_AMD_TRACE_FETCH_AT = idle lanes at which a wave of that kernel stops to refill
 static const int g_trace_fetch_at = env_int("RT_AMD_TRACE_FETCH_AT", rt::TRACE_FETCH_AT);
 // the same for the launch-per-level walks: nearest-hit and shadow walks
@@ -230,6 +234,13 @@ struct rt_scene {
   // records.
   bool eye_valid = false;
   float eye[3] = {0, 0, 0};
+  // Spheres by screen cell for the rays from the eye (k_bin_spheres): valid for one
+  // camera and frame size, rebuilt with the eye-relative records' protocol when
+  // either changes.  bins_use: this frame's launches read them.
+  DevBuf<int32_t> bins, bins_super; // bins_super: the first of the two levels they are made in
+  bool bins_valid = false, bins_use = false;
+  int bins_w = 0, bins_h = 0;
+  camera bins_cam = {};
   hipEvent_t ev_eye = nullptr, ev_frame = nullptr;
   bool frame_recorded = false;
   // bounce machinery, allocated on the first frame with bounces
@@ -289,6 +300,8 @@ struct rt_scene {
     d.tloose = use_tbvh ? tloose.p : nullptr;
     d.n_tleaf = use_tbvh ? (int)tleaf.n : 0;
     d.n_tloose = use_tbvh ? (int)tloose.n : 0;
+    d.bins = bins_use && use_bvh ? bins.p : nullptr;
+    d.bins_x = (bins_w + rt::BIN_PX - 1) / rt::BIN_PX;
     return d;
   }
 };
@@ -455,30 +468,70 @@ int scene_build(rt_scene *S, const scene_desc *s) {
   return RT_OK;
 }
 
-// Eye-relative records are rebuilt only when the eye moves.  Frames of one
-// scene may come in on different streams: a rebuild waits for the last frame's
-// launches (they read the old records), and every frame waits for the rebuild.
-int scene_set_eye(rt_scene *S, const camera *cam, hipStream_t st) {
-  if (S->eye_valid && memcmp(S->eye, cam->origin, sizeof S->eye) == 0) {
+rt::CameraDev camera_dev(const camera *cam, int w, int h);
+
+// Eye-relative records are rebuilt only when the eye moves, the spheres' lists by
+// screen cell when the camera or the frame size changes.  Frames of one scene may
+// come in on different streams: a rebuild waits for the last frame's launches (they
+// read the old records), and every frame waits for the rebuild.
+// may_allocate false (the entry point that allocates nothing): lists that exist
+// for this view are used, none are made.
+int scene_set_eye(rt_scene *S, const camera *cam, const rt_frame *fr, hipStream_t st,
+                  bool may_allocate) {
+  const bool eye_same = S->eye_valid && memcmp(S->eye, cam->origin, sizeof S->eye) == 0;
+  const bool want_bins = g_primary_bins && S->has_bvh && (S->screen == 1 || S->screen == 3) &&
+                         S->s_size >= kBinMinSpheres;
+  const bool bins_same = S->bins_valid && S->bins_w == fr->w && S->bins_h == fr->h &&
+                         memcmp(&S->bins_cam, cam, sizeof *cam) == 0;
+  S->bins_use = want_bins && bins_same;
+  const bool build_bins = want_bins && !bins_same && may_allocate;
+  if (eye_same && !build_bins) {
     HIP_TRY(hipStreamWaitEvent(st, S->ev_eye, 0)); // no-op on the stream that built them
     return RT_OK;
   }
   if (S->frame_recorded)
     HIP_TRY(hipStreamWaitEvent(st, S->ev_frame, 0));
-  rt::EyeArgs a;
-  a.sph_geo = S->sph_geo.p;
-  a.sph_prim = S->sph_prim.p;
-  a.tri = S->tri.p;
-  a.t_size = S->t_size;
-  a.s_size = S->s_size;
-  a.s_pad = S->s_pad;
-  a.ox = cam->origin[0];
-  a.oy = cam->origin[1];
-  a.oz = cam->origin[2];
-  HIP_TRY(rt::launch_prep_eye(a, st));
+  if (!eye_same) {
+    rt::EyeArgs a;
+    a.sph_geo = S->sph_geo.p;
+    a.sph_prim = S->sph_prim.p;
+    a.tri = S->tri.p;
+    a.t_size = S->t_size;
+    a.s_size = S->s_size;
+    a.s_pad = S->s_pad;
+    a.ox = cam->origin[0];
+    a.oy = cam->origin[1];
+    a.oz = cam->origin[2];
+    HIP_TRY(rt::launch_prep_eye(a, st));
+    memcpy(S->eye, cam->origin, sizeof S->eye);
+    S->eye_valid = true;
+  }
+  if (build_bins) {
+    const int bx = (fr->w + rt::BIN_PX - 1) / rt::BIN_PX, by = (fr->h + rt::BIN_PX - 1) / rt::BIN_PX;
+    const int sx = (fr->w + rt::BIN_SUPER_PX - 1) / rt::BIN_SUPER_PX,
+              sy = (fr->h + rt::BIN_SUPER_PX - 1) / rt::BIN_SUPER_PX;
+    const size_t words = (size_t)bx * by * rt::BIN_WORDS;
+    const size_t super_words = (size_t)sx * sy * rt::BIN_SUPER_WORDS;
+    S->bins_valid = false;
+    if (S->bins.n < words || S->bins_super.n < super_words) {
+      HIP_TRY(hipDeviceSynchronize()); // nothing may still read the old lists
+      if (S->bins.alloc(words) != hipSuccess || S->bins_super.alloc(super_words) != hipSuccess) {
+        (void)hipGetLastError();
+        S->bins.release(); // no lists: the walks serve the rays from the eye
+        S->bins_super.release();
+      }
+    }
+    if (S->bins.p) {
+      HIP_TRY(rt::launch_bin_spheres(S->dev(), camera_dev(cam, fr->w, fr->h), fr->w, fr->h,
+                                     S->bins.p, S->bins_super.p, st));
+      S->bins_valid = true;
+      S->bins_w = fr->w;
+      S->bins_h = fr->h;
+      S->bins_cam = *cam;
+      S->bins_use = true;
+    }
+  }
   HIP_TRY(hipEventRecord(S->ev_eye, st));
-  memcpy(S->eye, cam->origin, sizeof S->eye);
-  S->eye_valid = true;
   return RT_OK;
 }
 
@@ -947,7 +1000,7 @@ static int render_device_impl(rt_scene *S, const camera *cam, const rt_frame *fr
     if ((rc = ensure_arena(S, need)))
       return rc;
   }
-  if ((rc = scene_set_eye(S, cam, st)))
+  if ((rc = scene_set_eye(S, cam, fr, st, true)))
     return rc;
   rc = render_frame(S, &S->arena, S->side_stream ? S->side : nullptr, cam, fr, P, dev_ray_count,
                     dev_verify);
@@ -1045,7 +1098,7 @@ int rt_render_device_noalloc(rt_scene *S, const camera *cam, const rt_frame *fr,
     // zero (render_frame clears the control words and the overflow flag itself)
     HIP_TRY(hipMemsetAsync(A.extra, 0, need.frame_pixels * sizeof(unsigned long long), st));
   }
-  if ((rc = scene_set_eye(S, cam, st)))
+  if ((rc = scene_set_eye(S, cam, fr, st, false)))
     return rc;
   if ((rc = render_frame(S, &A, nullptr, cam, fr, P, dev_ray_count, nullptr)))
     return rc;

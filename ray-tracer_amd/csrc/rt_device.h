@@ -58,7 +58,19 @@ struct SceneDev {
   const TriLeaf *tleaf;      // the triangles in leaf order, with their indices
   const int32_t *tloose;     // triangles outside the hierarchy, tested by every ray
   int n_tleaf, n_tloose;
+  // Spheres by screen cell for the rays that leave the eye (k_bin_spheres), or
+  // nullptr: cell (x, y) of BIN_PX x BIN_PX pixels has the record
+  // bins[(y * bins_x + x) * BIN_WORDS ...] = {n, n sphere indices in rising order};
+  // n < 0: no list for this cell (too many spheres, or no cone could be formed).
+  const int32_t *bins;
+  int bins_x;
 };
+constexpr int BIN_PX = 16;
+constexpr int BIN_WORDS = 64;
+constexpr int BIN_CAP = BIN_WORDS - 1;
+constexpr int BIN_SUPER_PX = 128;     // the lists are made in two levels (k_bin_spheres)
+constexpr int BIN_SUPER_WORDS = 1024;
+static_assert(BIN_SUPER_PX % BIN_PX == 0, "a cell has one parent");
 
 struct CameraDev {
   double tan_half; // tan(fov*0.5*M_PI/180), evaluated on the host (renderer.cpp:35)
@@ -849,7 +861,8 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                                      float dz, float Xx = 0.f, float Xy = 0.f,
                                      float Xz = 0.f, float Dk = 0.f,
                                      ScreenStats st = ScreenStats{nullptr, nullptr, nullptr},
-                                     uint32_t *lds_stack = nullptr) {
+                                     uint32_t *lds_stack = nullptr,
+                                     const int32_t *bin_rec = nullptr) {
   float len_t = RT_INF, len_s = RT_INF;
   int idx_t = -1, idx_s = -1;
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
@@ -950,7 +963,38 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
     }
   }
 
-  if (BEAM == RT_ACCEL_BVH && sc.bvh != nullptr) {
+  if (BEAM == RT_ACCEL_BVH && FROM_EYE && !ANY_HIT && !VERIFY && bin_rec != nullptr) {
+    // Rays from the eye through one screen cell: the cell's list holds every sphere
+    // that the discriminant test (maths.cpp:132-133) can pass for any of them
+    // (k_bin_spheres), in rising index order, so the loop below is the plain loop of
+    // renderer.cpp:168-177 without the spheres that cannot matter.  The list and
+    // the records are the same for the whole wave: scalar loads.
+    const int n = bin_rec[0];
+    if (n >= 0) {
+      screened = true;
+      for (int k = 0; k < n; k++) {
+        const int idx = bin_rec[1 + k];
+        const float4 s = sc.sph_prim[idx];
+        const float b = 2.0f * dot3(dx, dy, dz, s.x, s.y, s.z); // maths.cpp:128
+        const float bb = b * b, ac = a4 * s.w;                  // maths.cpp:132
+        if (seek && !(bb < ac)) {
+          float Px, Py, Pz;
+          if (sphere_finish(a, b, s.w, bb, ac, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
+            const float len = length3(Px, Py, Pz);
+            if (len_s > len) { // renderer.cpp:170, strict
+              len_s = len;
+              idx_s = idx;
+              sPx = Px;
+              sPy = Py;
+              sPz = Pz;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (BEAM == RT_ACCEL_BVH && sc.bvh != nullptr && !screened) {
     // Per-lane walk.  Rays with a == 0 / NaN never yield an accepted sphere hit;
     // an a far outside [2^-40, 2^40] sends the whole wave to the plain loop.
     const bool sane = a > 9.094947e-13f && a < 1.0995116e12f;

@@ -137,6 +137,13 @@ struct CheckArgs {
 
 hipError_t launch_prep_scene(const PrepArgs &a, hipStream_t st);
 hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st);
+// Lists the spheres by screen cell of BIN_PX x BIN_PX pixels for the rays from the eye
+// of a w x h frame: bins holds ceil(w / BIN_PX) * ceil(h / BIN_PX) records of BIN_WORDS
+// words (rt_device.h, SceneDev::bins).
+// `super`: ceil(w / BIN_SUPER_PX) * ceil(h / BIN_SUPER_PX) records of BIN_SUPER_WORDS words
+// for the first of the two levels.
+hipError_t launch_bin_spheres(const SceneDev &sc, const CameraDev &cam, int w, int h, int32_t *bins,
+                              int32_t *super, hipStream_t st);
 // accel: RT_BEAM_NONE (plain loop), RT_BEAM_APEX (screen spheres per wave
 // before the per-ray tests) or RT_ACCEL_BVH (every lane walks the sphere
 // hierarchy); same results, different amounts of work.  verify_stats: device uint64[2] {spheres dropped although a ray's

@@ -421,8 +421,17 @@ __global__ __launch_bounds__(256, 5) void k_render(SceneDev sc, CameraDev cam,
   // the lanes' stacks of the sphere walk (rt_device.h, walk_spheres_lds)
   __shared__ uint32_t walk_words[ACCEL == RT_ACCEL_BVH ? LDS_STACK_ROWS * 256 : 1];
   uint32_t *const lds_stack = ACCEL == RT_ACCEL_BVH ? walk_words + threadIdx.x : nullptr;
+  // the screen cell of the wave's tile (a tile lies in one cell)
+  const int32_t *bin_rec = nullptr;
+  if (ACCEL == RT_ACCEL_BVH && sc.bins != nullptr) {
+    const int ti = band * f.band_rows + tile_in_band * 8, tj = (blockIdx.x * 4 + wave) * 8;
+    if (ti < f.h && tj < f.w)
+      bin_rec = sc.bins + (size_t)__builtin_amdgcn_readfirstlane(
+                              (ti / BIN_PX) * sc.bins_x + tj / BIN_PX) * BIN_WORDS;
+  }
   Hit h = trace<true, false, BM, VERIFY, TRI_TREE>(sc, inside, cam.ox, cam.oy, cam.oz, dx,
-                                         dy, dz, cam.ox, cam.oy, cam.oz, 0.f, st, lds_stack);
+                                         dy, dz, cam.ox, cam.oy, cam.oz, 0.f, st, lds_stack,
+                                         bin_rec);
 
   uint32_t fb0 = 0, fb1 = 0, fb2 = 0; // renderer.cpp:50-52
   uint32_t n_rays = inside ? 1u : 0u;
@@ -454,6 +463,73 @@ __global__ __launch_bounds__(256, 5) void k_render(SceneDev sc, CameraDev cam,
       f.ids[p] = h.kind == 0 ? -1 : (h.kind == 1 ? h.index : sc.t_size + h.index);
   }
   add_ray_count(f.ray_count, n_rays);
+}
+
+// ---------------------------------------------------------------------------
+// k_bin_spheres — spheres by screen cell, for the rays that leave the eye
+// ---------------------------------------------------------------------------
+// One wave per cell of PX x PX pixels.  The rays of the cell's four corner
+// pixels are generated exactly as k_render generates them; the pixels of the cell
+// lie in the convex hull of the corners on the image plane and the set of points
+// of a plane seen from the eye within an angle of an axis is convex, so the cone of
+// make_beam around the four corner rays (inflated there by far more than the
+// rounding of a direction) holds every ray of the cell.  The spheres are screened
+// against it 64 at a time with the test of the beam screen (beam_keeps: never drops
+// a sphere whose discriminant test can pass for a line of the cone through the
+// apex) and the kept ones listed in rising index order.
+// Two levels, so that a change of camera costs a few microseconds: cells of
+// BIN_SUPER_PX pixels screen all the spheres (FROM_LIST false), the cells of BIN_PX
+// pixels then only their parent's list (a cell's rays are among its parent's, so
+// the parent's list holds every sphere one of them can hit, and the cell's own
+// screen drops none of those).  A parent without a list leaves its children
+// without one: those tiles walk the hierarchy.
+template <int PX, int WORDS, bool FROM_LIST>
+__global__ __launch_bounds__(64) void k_bin_spheres(SceneDev sc, CameraDev cam, int w, int h,
+                                                    int32_t *out, int out_x,
+                                                    const int32_t *parent, int parent_x) {
+  const int lane = threadIdx.x;
+  const int j0 = blockIdx.x * PX, i0 = blockIdx.y * PX;
+  const int j1 = j0 + PX - 1 < w ? j0 + PX - 1 : w - 1;
+  const int i1 = i0 + PX - 1 < h ? i0 + PX - 1 : h - 1;
+  const int i = (lane & 2) ? i1 : i0, j = (lane & 1) ? j1 : j0;
+  // renderer.cpp:34-44 as in k_render
+  float px = (float)((2 * ((j + 0.5) / (double)(float)w) - 1) * cam.tan_half * (double)cam.aspect);
+  float py = (float)((1 - 2 * ((i + 0.5) / (double)(float)h)) * cam.tan_half);
+  float dx = px - cam.ox, dy = py - cam.oy, dz = cam.plane_z - cam.oz;
+  normalize3(dx, dy, dz);
+  const bool lv = lane < 4;
+  const float a = dot3(dx, dy, dz, dx, dy, dz);
+  const Beam B = make_beam(lv, a, dx, dy, dz, cam.ox, cam.oy, cam.oz, 0.f, 9.5367431640625e-07f);
+  int32_t *const rec = out + ((size_t)blockIdx.y * out_x + blockIdx.x) * WORDS;
+  const int32_t *src = nullptr;
+  int n_src = sc.s_size;
+  if (FROM_LIST) {
+    src = parent + ((size_t)(i0 / BIN_SUPER_PX) * parent_x + j0 / BIN_SUPER_PX) * BIN_SUPER_WORDS;
+    n_src = src[0];
+  }
+  if (!B.narrow || n_src < 0) {
+    if (lane == 0)
+      rec[0] = -1;
+    return;
+  }
+  int n = 0;
+  for (int base = 0; base < n_src; base += 64) {
+    const int k = base + lane;
+    int idx = k < n_src ? k : n_src - 1;
+    if (FROM_LIST)
+      idx = src[1 + idx];
+    const float4 g = sc.sph_geo[idx];
+    const bool keep = k < n_src && beam_keeps(B, g);
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (pos < WORDS - 1)
+        rec[1 + pos] = idx;
+    }
+    n += __builtin_popcountll(m);
+  }
+  if (lane == 0)
+    rec[0] = n <= WORDS - 1 ? n : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -620,6 +696,19 @@ hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st) {
   if (n <= 0)
     return hipSuccess;
   hipLaunchKernelGGL(k_prep_eye, dim3((n + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_bin_spheres(const SceneDev &sc, const CameraDev &cam, int w, int h, int32_t *bins,
+                              int32_t *super, hipStream_t st) {
+  if (w <= 0 || h <= 0 || sc.s_size <= 0 || !bins || !super)
+    return hipErrorInvalidValue;
+  const int bx = (w + BIN_PX - 1) / BIN_PX, by = (h + BIN_PX - 1) / BIN_PX;
+  const int sx = (w + BIN_SUPER_PX - 1) / BIN_SUPER_PX, sy = (h + BIN_SUPER_PX - 1) / BIN_SUPER_PX;
+  hipLaunchKernelGGL((k_bin_spheres<BIN_SUPER_PX, BIN_SUPER_WORDS, false>), dim3(sx, sy), dim3(64), 0,
+                     st, sc, cam, w, h, super, sx, (const int32_t *)nullptr, 0);
+  hipLaunchKernelGGL((k_bin_spheres<BIN_PX, BIN_WORDS, true>), dim3(bx, by), dim3(64), 0, st, sc,
+                     cam, w, h, bins, bx, (const int32_t *)super, sx);
   return hipGetLastError();
 }
 
