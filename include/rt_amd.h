@@ -214,14 +214,22 @@ int rt_scene_set_arena_limit(rt_scene *scene, uint64_t max_bytes);
 
 /* ---- work avoidance (no counterpart in the reference) ----------------------
  * The reference tests every ray against every primitive (renderer.cpp:156-177).
- * The library gets the same answers with far fewer tests, in three ways:
+ * The library gets the same answers with far fewer tests, in four ways:
  *   - beam screen: a wave's rays that share an apex (primary rays: the eye;
  *     shadow rays: the light) are bounded by a cone, the spheres are screened
  *     64 at a time (one per lane) against that cone, and the reference's per-ray
  *     arithmetic runs only on spheres the cone can touch;
  *   - sphere hierarchy: a tree of boxes built at rt_scene_create; each
- *     lane walks it for its own ray (bounce rays, bulk queries, and by default
+ *     lane walks it for its own ray (bounce rays, bulk queries, and in mode 3
  *     also primary and shadow rays);
+ *   - sphere lists (scenes with 64 spheres or more, mode 1): per cell of 16 x 16
+ *     pixels the spheres that the cone of the cell's rays from the eye can touch,
+ *     made anew when the camera or the frame size changes (two small kernels); and
+ *     per direction from each of the first four lights (a cube of 6 x 256 x 256
+ *     cells, 25 MB per light, made at rt_scene_create) the spheres that a shadow
+ *     ray towards that light can touch.  Both by the beam screen's test.  The rays
+ *     of a tile then run the reference's loop over a list of a handful of spheres
+ *     instead of walking the tree;
  *   - triangle hierarchy: scenes with 16 or more triangles get a tree over the
  *     triangles as well, with bounds that follow the reference's own triangle
  *     arithmetic (maths.cpp:77-78: the test is the textbook one seen from the ray
@@ -229,8 +237,9 @@ int rt_scene_set_arena_limit(rt_scene *scene, uint64_t max_bytes);
  *     normal).
  * All are conservative by construction, so images, ids and ray counts are
  * identical in every mode.  mode: 0 = plain loop, every ray against every
- * primitive (used to measure the brute-force roofline); 1 = automatic (default);
- * 2 = beam screen for primary/shadow rays; 3 = hierarchy for all rays.
+ * primitive (used to measure the brute-force roofline); 1 = automatic (default:
+ * the lists for primary rays and their shadow rays, the hierarchies for all
+ * other rays); 2 = beam screen for primary/shadow rays; 3 = hierarchy for all rays.
  * The mode belongs to a scene: rt_scene_set_screen changes it for later frames
  * of that scene; rt_set_screen sets the mode that scenes created afterwards
  * start with (gpu_render* create theirs inside the call).                     */
@@ -275,7 +284,10 @@ int rt_scene_kernel_times(rt_scene *scene, float ms[3]);
  * nodes; deeper ones use per-lane stacks in scratch memory), info[3] 1 if a frame
  * with bounces runs its bounce levels as one launch (rt_scene_set_one_launch and
  * the conditions listed there), info[4] nodes of the triangle hierarchy (0:
- * none), info[5..7] 0.                                                         */
+ * none), info[5] lights that have sphere lists by direction, info[6] screen cells
+ * that have a sphere list for the view of the last frame (-1: no lists were made),
+ * info[7] direction cells of those lights that have no list (-1: no lists).
+ * info[6..7] wait for the device and copy the lists to the host.                */
 int rt_scene_describe(const rt_scene *scene, int64_t info[8]);
 
 /* As rt_render_device, with a slow self-checking build of the kernel that

@@ -79,7 +79,6 @@ constexpr size_t kRowWords = (size_t)rt::QUEUE_SEGMENTS * rt::CTL_WORDS;
 constexpr size_t kMaxBouncePixels = (size_t)1 << 26;
 constexpr size_t kSmallSharePixels = 1500000; // see bounce_needs
 constexpr size_t kCheckPinnedRays = 256;      // see gpu_check_intersection
-constexpr int kBinMinSpheres = 64;            // scenes with fewer spheres get no lists by screen cell
 
 // Measurement knobs of the one-launch bounce kernel, read once from the environment
 // (tools/ only; the defaults are what ships): RT_AMD_TRACE_SMALL_GRID = percent of the
@@ -94,6 +93,11 @@ static const int g_trace_small_pixels = env_int("RT_AMD_TRACE_SMALL_PIXELS", (in
 // RT_AMD_PRIMARY_BINS = 0: the rays from the eye walk the sphere hierarchy like all others
 // (measurement only; what ships lists the spheres by screen cell, k_bin_spheres).
 static const int g_primary_bins = env_int("RT_AMD_PRIMARY_BINS", 1);
+// Scenes with fewer spheres get no lists by screen cell or by light direction: their
+// tree is a handful of nodes.  RT_AMD_LIST_MIN_SPHERES lowers that for tests.
+static const int kBinMinSpheres = env_int("RT_AMD_LIST_MIN_SPHERES", 64);
+// RT_AMD_LIGHT_CELLS = 0: the primary hits' shadow rays walk the hierarchy too.
+static const int g_light_cells = env_int("RT_AMD_LIGHT_CELLS", 1);
 // RT_AMD_TRACE_FETCH_AT = idle lanes at which a wave of that kernel stops to refill
 static const int g_trace_fetch_at = env_int("RT_AMD_TRACE_FETCH_AT", rt::TRACE_FETCH_AT);
 // the same for the launch-per-level walks: nearest-hit and shadow walks
@@ -238,6 +242,10 @@ struct rt_scene {
   // camera and frame size, rebuilt with the eye-relative records' protocol when
   // either changes.  bins_use: this frame's launches read them.
   DevBuf<int32_t> bins, bins_super; // bins_super: the first of the two levels they are made in
+  // Spheres by direction from the first lights (k_bin_light), made with the scene
+  DevBuf<int32_t> lcells;
+  int lcell_lights = 0;
+  float lcell_reach[rt::LCELL_MAX_LIGHTS] = {0, 0, 0, 0};
   bool bins_valid = false, bins_use = false;
   int bins_w = 0, bins_h = 0;
   camera bins_cam = {};
@@ -302,6 +310,11 @@ struct rt_scene {
     d.n_tloose = use_tbvh ? (int)tloose.n : 0;
     d.bins = bins_use && use_bvh ? bins.p : nullptr;
     d.bins_x = (bins_w + rt::BIN_PX - 1) / rt::BIN_PX;
+    const bool use_cells = use_bvh && lcell_lights > 0 && screen == 1;
+    d.lcells = use_cells ? lcells.p : nullptr;
+    d.lcell_lights = use_cells ? lcell_lights : 0;
+    for (int k = 0; k < rt::LCELL_MAX_LIGHTS; k++)
+      d.lcell_reach[k] = lcell_reach[k];
     return d;
   }
 };
@@ -456,6 +469,39 @@ int scene_build(rt_scene *S, const scene_desc *s) {
       HIP_TRY(hipStreamSynchronize(nullptr)); // `order` dies here
     }
   }
+  // spheres by direction from the first lights, for the shadow rays of the primary hits
+  if (g_light_cells && S->has_bvh && s->s_size >= kBinMinSpheres && s->l_size > 0) {
+    const int nl = s->l_size < rt::LCELL_MAX_LIGHTS ? s->l_size : rt::LCELL_MAX_LIGHTS;
+    DevBuf<int32_t> super;
+    if (S->lcells.alloc((size_t)nl * rt::LCELL_COUNT * rt::LCELL_WORDS) == hipSuccess &&
+        super.alloc((size_t)6 * rt::LCELL_SUPER_R * rt::LCELL_SUPER_R * rt::LCELL_SUPER_WORDS) ==
+            hipSuccess) {
+      const rt::SceneDev sd = S->dev();
+      for (int l = 0; l < nl; l++) {
+        const float *X = s->lights + 3 * l;
+        // how far from the light a point of a sphere's surface can be, with room for
+        // the rounding of a hit point
+        double reach = 0;
+        for (int i = 0; i < s->s_size; i++) {
+          const double dx = (double)s->spheres[3 * i] - X[0], dy = (double)s->spheres[3 * i + 1] - X[1],
+                       dz = (double)s->spheres[3 * i + 2] - X[2];
+          reach = std::max(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)s->radius[i]));
+        }
+        reach = reach * 1.01 + 0.01;
+        if (!(reach < 1e18) || !std::isfinite(X[0]) || !std::isfinite(X[1]) || !std::isfinite(X[2]))
+          break;
+        S->lcell_reach[l] = (float)reach;
+        HIP_TRY(rt::launch_bin_light(sd, X[0], X[1], X[2], (float)reach,
+                                     S->lcells.p + (size_t)l * rt::LCELL_COUNT * rt::LCELL_WORDS,
+                                     super.p, nullptr));
+        S->lcell_lights = l + 1;
+      }
+      HIP_TRY(hipStreamSynchronize(nullptr)); // `super` dies here
+    } else {
+      (void)hipGetLastError();
+      S->lcells.release(); // no lists: the shadow rays walk the hierarchy
+    }
+  }
   HIP_TRY(hipStreamSynchronize(nullptr)); // staging buffers die here
   S->eye_valid = false;
   S->screen = g_default_screen.load();
@@ -479,8 +525,7 @@ rt::CameraDev camera_dev(const camera *cam, int w, int h);
 int scene_set_eye(rt_scene *S, const camera *cam, const rt_frame *fr, hipStream_t st,
                   bool may_allocate) {
   const bool eye_same = S->eye_valid && memcmp(S->eye, cam->origin, sizeof S->eye) == 0;
-  const bool want_bins = g_primary_bins && S->has_bvh && (S->screen == 1 || S->screen == 3) &&
-                         S->s_size >= kBinMinSpheres;
+  const bool want_bins = g_primary_bins && S->has_bvh && S->screen == 1 && S->s_size >= kBinMinSpheres;
   const bool bins_same = S->bins_valid && S->bins_w == fr->w && S->bins_h == fr->h &&
                          memcmp(&S->bins_cam, cam, sizeof *cam) == 0;
   S->bins_use = want_bins && bins_same;
@@ -1187,6 +1232,31 @@ int rt_scene_describe(const rt_scene *S, int64_t info[8]) {
   info[2] = bvh_fits_lds(S) ? 1 : 0;
   info[3] = uses_trace(S) ? 1 : 0;
   info[4] = S->has_tbvh ? (int64_t)S->tbvh_nodes : 0;
+  // the sphere lists (waits for the device and copies them: an inspection call)
+  info[5] = S->lcell_lights;
+  info[6] = info[7] = -1;
+  if (S->bins_valid || S->lcell_lights > 0) {
+    HIP_TRY(hipSetDevice(S->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<int32_t> host;
+    if (S->bins_valid) {
+      const size_t cells = (size_t)((S->bins_w + rt::BIN_PX - 1) / rt::BIN_PX) *
+                           ((S->bins_h + rt::BIN_PX - 1) / rt::BIN_PX);
+      host.resize(cells * rt::BIN_WORDS);
+      HIP_TRY(hipMemcpy(host.data(), S->bins.p, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      info[6] = 0;
+      for (size_t c = 0; c < cells; c++)
+        info[6] += host[c * rt::BIN_WORDS] >= 0;
+    }
+    if (S->lcell_lights > 0) {
+      const size_t cells = (size_t)S->lcell_lights * rt::LCELL_COUNT;
+      host.resize(cells * rt::LCELL_WORDS);
+      HIP_TRY(hipMemcpy(host.data(), S->lcells.p, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      info[7] = 0;
+      for (size_t c = 0; c < cells; c++)
+        info[7] += host[c * rt::LCELL_WORDS] < 0;
+    }
+  }
   return RT_OK;
 }
 

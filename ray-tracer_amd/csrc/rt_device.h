@@ -64,7 +64,23 @@ struct SceneDev {
   // n < 0: no list for this cell (too many spheres, or no cone could be formed).
   const int32_t *bins;
   int bins_x;
+  // Spheres by direction as seen from a light, for the shadow rays that aim at it
+  // (k_bin_light), or nullptr.  The directions from the light are the cells of a cube:
+  // six faces of LCELL_R x LCELL_R cells; cell c of light l has the record
+  // lcells[(l * LCELL_COUNT + c) * LCELL_WORDS ...] = {n, n sphere indices}, n < 0: no
+  // list.  A list serves rays that start within lcell_reach[l] of the light; lights
+  // from lcell_lights on have no lists.
+  const int32_t *lcells;
+  int lcell_lights;
+  float lcell_reach[4];
 };
+constexpr int LCELL_MAX_LIGHTS = 4;
+constexpr int LCELL_R = 256;
+constexpr int LCELL_COUNT = 6 * LCELL_R * LCELL_R;
+constexpr int LCELL_WORDS = 16;
+constexpr int LCELL_SUPER_R = 32; // the lists are made in two levels (k_bin_light)
+constexpr int LCELL_SUPER_WORDS = 256;
+static_assert(LCELL_R % LCELL_SUPER_R == 0, "a cell has one parent");
 constexpr int BIN_PX = 16;
 constexpr int BIN_WORDS = 64;
 constexpr int BIN_CAP = BIN_WORDS - 1;
@@ -852,6 +868,38 @@ __device__ __forceinline__ void walk_spheres_lds(const SceneDev &sc, uint32_t *s
   }
 }
 
+// The cell (of an R x R x 6 cube around the light) of the direction v from the light.
+// Face = the largest component and its sign; the other two, divided by it, run over
+// [-1, 1].  A direction within an ulp of a cell's edge may be given to the neighbour:
+// the cells' cones are inflated by a hundred times that (make_beam).
+template <int R>
+__device__ __forceinline__ int light_cell(float vx, float vy, float vz) {
+  const float ax = fabsf(vx), ay = fabsf(vy), az = fabsf(vz);
+  int face;
+  float m, u, w;
+  if (ax >= ay && ax >= az) {
+    face = vx < 0.f ? 1 : 0;
+    m = ax;
+    u = vy;
+    w = vz;
+  } else if (ay >= az) {
+    face = vy < 0.f ? 3 : 2;
+    m = ay;
+    u = vx;
+    w = vz;
+  } else {
+    face = vz < 0.f ? 5 : 4;
+    m = az;
+    u = vx;
+    w = vy;
+  }
+  const float s = (0.5f * R) / m;
+  int cu = (int)fmaf(u, s, 0.5f * R), cw = (int)fmaf(w, s, 0.5f * R);
+  cu = cu < 0 ? 0 : (cu > R - 1 ? R - 1 : cu);
+  cw = cw < 0 ? 0 : (cw > R - 1 ? R - 1 : cw);
+  return (face * R + cw) * R + cu;
+}
+
 // TRI_TREE false: the caller knows that the scene has no triangle hierarchy, and the
 // kernel then carries no triangle walk (its code and stack cost the sphere-only
 // primary pass 3 % even when it never runs).
@@ -862,7 +910,7 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
                                      float Xz = 0.f, float Dk = 0.f,
                                      ScreenStats st = ScreenStats{nullptr, nullptr, nullptr},
                                      uint32_t *lds_stack = nullptr,
-                                     const int32_t *bin_rec = nullptr) {
+                                     const int32_t *bin_rec = nullptr, int cell_light = -1) {
   float len_t = RT_INF, len_s = RT_INF;
   int idx_t = -1, idx_s = -1;
   float tPx = 0, tPy = 0, tPz = 0, sPx = 0, sPy = 0, sPz = 0;
@@ -991,6 +1039,51 @@ __device__ __forceinline__ Hit trace(const SceneDev &sc, bool live, float ox,
           }
         }
       }
+    }
+  }
+
+  if (BEAM == RT_ACCEL_BVH && !FROM_EYE && ANY_HIT && !VERIFY && cell_light >= 0 &&
+      sc.lcells != nullptr) {
+    // Shadow rays towards light `cell_light` (the apex X): the list of the cell that
+    // holds the direction from the light to a ray's origin has every sphere the ray's
+    // discriminant test can pass for (k_bin_light), provided the origin is within the
+    // lists' reach.  The wave runs the reference's test on the lists of all the cells
+    // its lanes fall into, every lane on every sphere (a sphere that is not in a lane's
+    // own list cannot be hit by it, and the test says so).  A cell without a list or
+    // an origin out of reach sends the lanes still seeking to the walk below.
+    const bool lv = seek && (a > 0.f);
+    if (!__any(lv && !(Dk <= sc.lcell_reach[cell_light]))) {
+      const int32_t *const cells = sc.lcells + (size_t)cell_light * LCELL_COUNT * LCELL_WORDS;
+      const int cell = lv ? light_cell<LCELL_R>(ox - Xx, oy - Xy, oz - Xz) : -1;
+      bool want = lv, complete = true;
+      unsigned long long todo = __ballot(lv);
+      while (todo != 0 && complete) {
+        const int c = __builtin_amdgcn_readlane(cell, __builtin_ctzll(todo));
+        todo &= ~__ballot(cell == c);
+        const int32_t *const rec = cells + (size_t)c * LCELL_WORDS;
+        const int n = rec[0];
+        complete = n >= 0;
+        for (int k = 0; k < n && __any(want); k++) {
+          const int idx = rec[1 + k];
+          const float4 g = sc.sph_geo[idx];
+          float Px, Py, Pz;
+          if (want && sphere_exact(g.x, g.y, g.z, g.w, a, a4, ox, oy, oz, dx, dy, dz, Px, Py, Pz)) {
+            const float len = length3(Px, Py, Pz);
+            if (len_s > len) { // renderer.cpp:170: a |P| that is not below +inf is no hit
+              len_s = len;
+              idx_s = idx;
+              sPx = Px;
+              sPy = Py;
+              sPz = Pz;
+              want = false;
+            }
+          }
+        }
+      }
+      if (complete)
+        screened = true;
+      else
+        seek = seek && idx_s < 0;
     }
   }
 

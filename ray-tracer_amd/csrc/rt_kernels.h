@@ -144,6 +144,12 @@ hipError_t launch_prep_eye(const EyeArgs &a, hipStream_t st);
 // for the first of the two levels.
 hipError_t launch_bin_spheres(const SceneDev &sc, const CameraDev &cam, int w, int h, int32_t *bins,
                               int32_t *super, hipStream_t st);
+// Lists the spheres by direction from the light X for shadow rays that start within
+// `reach` of it: cells holds LCELL_COUNT records of LCELL_WORDS words (rt_device.h,
+// SceneDev::lcells), super 6 * LCELL_SUPER_R^2 records of LCELL_SUPER_WORDS words for
+// the first of the two levels.
+hipError_t launch_bin_light(const SceneDev &sc, float Xx, float Xy, float Xz, float reach,
+                            int32_t *cells, int32_t *super, hipStream_t st);
 // accel: RT_BEAM_NONE (plain loop), RT_BEAM_APEX (screen spheres per wave
 // before the per-ray tests) or RT_ACCEL_BVH (every lane walks the sphere
 // hierarchy); same results, different amounts of work.  verify_stats: device uint64[2] {spheres dropped although a ray's

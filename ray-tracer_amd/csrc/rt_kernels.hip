@@ -313,7 +313,8 @@ shade_hits(const SceneDev &sc, const BounceDev &bd, bool hit, const Hit &h,
       // shadow rays of the wave aim at the light: that is the beam's apex.
       Hit sh = trace<false, true, BEAM, VERIFY, TRI_TREE>(sc, cast, h.Px, h.Py, h.Pz, lx, ly,
                                                 lz, light.x, light.y, light.z,
-                                                dist, st, lds_stack);
+                                                dist, st, lds_stack, nullptr,
+                                                l < sc.lcell_lights ? l : -1);
       if (cast) {
         n_rays++;
         if (sh.kind == 0) {
@@ -533,6 +534,63 @@ __global__ __launch_bounds__(64) void k_bin_spheres(SceneDev sc, CameraDev cam, 
 }
 
 // ---------------------------------------------------------------------------
+// k_bin_light — spheres by direction from a light, for the shadow rays aimed at it
+// ---------------------------------------------------------------------------
+// One wave per cell of an R x R x 6 cube of directions around the light X (grid
+// R x R x 6).  A cell is a rectangle on a face of the cube, so the cone of
+// make_beam around its four corner directions holds every direction of the cell
+// (as for k_bin_spheres); the lines it stands for are the shadow rays
+// {P + t d}, d = normalize(X - P) in float, that start within `reach` of X in that
+// cell: make_beam's slack K and widening delta are taken for that distance.
+// Two levels as in k_bin_spheres.
+template <int R, int WORDS, bool FROM_LIST>
+__global__ __launch_bounds__(64) void k_bin_light(SceneDev sc, float Xx, float Xy, float Xz,
+                                                  float reach, int32_t *out,
+                                                  const int32_t *parent) {
+  const int lane = threadIdx.x;
+  const int cu = blockIdx.x, cw = blockIdx.y, face = blockIdx.z;
+  const float u = ((lane & 1) ? cu + 1 : cu) * (2.0f / R) - 1.0f;
+  const float w = ((lane & 2) ? cw + 1 : cw) * (2.0f / R) - 1.0f;
+  const float m = (face & 1) ? -1.0f : 1.0f;
+  float dx = face < 2 ? m : u, dy = face < 2 ? u : (face < 4 ? m : w), dz = face < 4 ? w : m;
+  normalize3(dx, dy, dz);
+  const bool lv = lane < 4;
+  const float a = dot3(dx, dy, dz, dx, dy, dz);
+  const Beam B = make_beam(lv, a, dx, dy, dz, Xx, Xy, Xz, reach, 9.5367431640625e-07f);
+  int32_t *const rec = out + ((size_t)(face * R + cw) * R + cu) * WORDS;
+  const int32_t *src = nullptr;
+  int n_src = sc.s_size;
+  if (FROM_LIST) {
+    constexpr int F = LCELL_R / LCELL_SUPER_R;
+    src = parent + ((size_t)(face * LCELL_SUPER_R + cw / F) * LCELL_SUPER_R + cu / F) * LCELL_SUPER_WORDS;
+    n_src = src[0];
+  }
+  if (!B.narrow || n_src < 0) {
+    if (lane == 0)
+      rec[0] = -1;
+    return;
+  }
+  int n = 0;
+  for (int base = 0; base < n_src; base += 64) {
+    const int k = base + lane;
+    int idx = k < n_src ? k : n_src - 1;
+    if (FROM_LIST)
+      idx = src[1 + idx];
+    const float4 g = sc.sph_geo[idx];
+    const bool keep = k < n_src && beam_keeps(B, g);
+    const unsigned long long mk = __ballot(keep);
+    if (keep) {
+      const int pos = n + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+      if (pos < WORDS - 1)
+        rec[1 + pos] = idx;
+    }
+    n += __builtin_popcountll(mk);
+  }
+  if (lane == 0)
+    rec[0] = n <= WORDS - 1 ? n : -1;
+}
+
+// ---------------------------------------------------------------------------
 // k_bounce — one bounce level: one queued ray per lane
 // ---------------------------------------------------------------------------
 // The grid is fixed; waves stride over the queue, whose length is read from
@@ -709,6 +767,18 @@ hipError_t launch_bin_spheres(const SceneDev &sc, const CameraDev &cam, int w, i
                      st, sc, cam, w, h, super, sx, (const int32_t *)nullptr, 0);
   hipLaunchKernelGGL((k_bin_spheres<BIN_PX, BIN_WORDS, true>), dim3(bx, by), dim3(64), 0, st, sc,
                      cam, w, h, bins, bx, (const int32_t *)super, sx);
+  return hipGetLastError();
+}
+
+hipError_t launch_bin_light(const SceneDev &sc, float Xx, float Xy, float Xz, float reach,
+                            int32_t *cells, int32_t *super, hipStream_t st) {
+  if (sc.s_size <= 0 || !cells || !super || !(reach > 0.f))
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_bin_light<LCELL_SUPER_R, LCELL_SUPER_WORDS, false>),
+                     dim3(LCELL_SUPER_R, LCELL_SUPER_R, 6), dim3(64), 0, st, sc, Xx, Xy, Xz, reach,
+                     super, (const int32_t *)nullptr);
+  hipLaunchKernelGGL((k_bin_light<LCELL_R, LCELL_WORDS, true>), dim3(LCELL_R, LCELL_R, 6), dim3(64),
+                     0, st, sc, Xx, Xy, Xz, reach, cells, (const int32_t *)super);
   return hipGetLastError();
 }
 

@@ -355,7 +355,9 @@ class DeviceScene:
         info = (C.c_int64 * 8)()
         _check(lib().rt_scene_describe(self.handle, info))
         return {"sphere_nodes": info[0], "sphere_levels": info[1], "lds_stacks": bool(info[2]),
-                "one_launch": bool(info[3]), "triangle_nodes": info[4]}
+                "one_launch": bool(info[3]), "triangle_nodes": info[4],
+                "lights_with_lists": info[5], "screen_cells_with_list": info[6],
+                "light_cells_without_list": info[7]}
 
     def time_kernels(self, on: bool = True):
         """rt_scene_time_kernels: record events around the stages of later frames."""
