@@ -225,8 +225,8 @@ int rt_scene_set_arena_limit(rt_scene *scene, uint64_t max_bytes);
  *   - sphere lists (scenes with 64 spheres or more, mode 1): per cell of 16 x 16
  *     pixels the spheres that the cone of the cell's rays from the eye can touch,
  *     made anew when the camera or the frame size changes (two small kernels); and
- *     per direction from each of the first four lights (a cube of 6 x 256 x 256
- *     cells, 25 MB per light, made at rt_scene_create) the spheres that a shadow
+ *     per direction from each of the first four lights (a cube of 6 x 128 x 128
+ *     cells, 12.6 MB per light, made at rt_scene_create) the spheres that a shadow
  *     ray towards that light can touch.  Both by the beam screen's test.  The rays
  *     of a tile then run the reference's loop over a list of a handful of spheres
  *     instead of walking the tree;

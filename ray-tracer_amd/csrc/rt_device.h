@@ -75,12 +75,15 @@ struct SceneDev {
   float lcell_reach[4];
 };
 constexpr int LCELL_MAX_LIGHTS = 4;
-constexpr int LCELL_R = 256;
+// 64 / 128 / 192 / 256 / 512 cells along a face: the depth-1 4K frame of 10 000 spheres takes
+// 0.286 / 0.271 / 0.269 / 0.279 / 0.316 ms (fewer, longer lists against more cells per tile).
+constexpr int LCELL_R = 128;
 constexpr int LCELL_COUNT = 6 * LCELL_R * LCELL_R;
-constexpr int LCELL_WORDS = 16;
-constexpr int LCELL_SUPER_R = 32; // the lists are made in two levels (k_bin_light)
+constexpr int LCELL_WORDS = 32;
+constexpr int LCELL_SUPER_R = 16; // the lists are made in two levels (k_bin_light)
 constexpr int LCELL_SUPER_WORDS = 256;
 static_assert(LCELL_R % LCELL_SUPER_R == 0, "a cell has one parent");
+// cells of 8 / 16 / 32 pixels: 0.283 / 0.277 / 0.281 ms for that frame
 constexpr int BIN_PX = 16;
 constexpr int BIN_WORDS = 64;
 constexpr int BIN_CAP = BIN_WORDS - 1;
