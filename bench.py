@@ -315,6 +315,36 @@ def main():
     stage_ms = staged_frames(min(10, max(2, args.steps)))
     one_frame_ms = float(sum(stage_ms))
 
+    # ---- the same frames with a camera that moves every frame (not part of `value`) ----
+    # The spheres' lists by screen cell and the eye-relative records belong to one
+    # view; the timed frames above share theirs, like any still camera.  Here they
+    # are made anew for every frame.
+    def moving_camera_frames(n):
+        sl = slots[0]
+        cams = [rtamd.default_camera(), rtamd.default_camera()]
+        cams[1].origin[0] += 1e-3
+        with torch.cuda.stream(sl.stream):
+            for k in range(2):
+                sl.scene.render_device(sl.fb.data_ptr(), None, w, h, max_depth=depth, cam=cams[k],
+                                       band_rows=band_rows, band_index=rank, band_count=world,
+                                       stream=sl.stream.cuda_stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n):
+                sl.scene.render_device(sl.fb.data_ptr(), None, w, h, max_depth=depth,
+                                       cam=cams[k % 2], band_rows=band_rows, band_index=rank,
+                                       band_count=world, stream=sl.stream.cuda_stream)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            # back to the bench's own view
+            sl.scene.render_device(sl.fb.data_ptr(), None, w, h, max_depth=depth,
+                                   band_rows=band_rows, band_index=rank, band_count=world,
+                                   stream=sl.stream.cuda_stream)
+            torch.cuda.synchronize()
+        return ms
+
+    moving_ms = moving_camera_frames(max(4, min(20, args.steps)))
+
     # ---- N > 1: the same split with four frames in flight, beside `value` ----
     in_flight = None
     if world > 1 and n_buf == 1 and not args.no_in_flight_leg:
@@ -353,6 +383,10 @@ def main():
             # gather: sum of the three stages
             "one_frame_ms": one_frame_ms,
             "one_frame_mrays_per_s": my_rays_per_frame / (one_frame_ms * 1e-3) / 1e6,
+            # the records that belong to a view (eye-relative spheres, sphere lists by
+            # screen cell) are kept while the camera stands still, as in the timed frames
+            "view_records": {"kept_while_the_camera_stands_still": True,
+                             "ms_per_frame_with_a_camera_that_moves_every_frame": moving_ms},
         }
         if in_flight is not None:
             out["frames_in_flight_4"] = in_flight

@@ -524,13 +524,15 @@ __global__ __launch_bounds__(64) void k_bin_spheres(SceneDev sc, CameraDev cam, 
     const unsigned long long m = __ballot(keep);
     if (keep) {
       const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      if (pos < WORDS - 1)
+      if (pos < WORDS - LIST_GROUP)
         rec[1 + pos] = idx;
     }
     n += __builtin_popcountll(m);
   }
+  if (n <= WORDS - LIST_GROUP && lane < LIST_GROUP && n + lane < ((n + LIST_GROUP - 1) & ~(LIST_GROUP - 1)))
+    rec[1 + n + lane] = 0; // the readers take LIST_GROUP entries at a time
   if (lane == 0)
-    rec[0] = n <= WORDS - 1 ? n : -1;
+    rec[0] = n <= WORDS - LIST_GROUP ? n : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -581,13 +583,15 @@ __global__ __launch_bounds__(64) void k_bin_light(SceneDev sc, float Xx, float X
     const unsigned long long mk = __ballot(keep);
     if (keep) {
       const int pos = n + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
-      if (pos < WORDS - 1)
+      if (pos < WORDS - LIST_GROUP)
         rec[1 + pos] = idx;
     }
     n += __builtin_popcountll(mk);
   }
+  if (n <= WORDS - LIST_GROUP && lane < LIST_GROUP && n + lane < ((n + LIST_GROUP - 1) & ~(LIST_GROUP - 1)))
+    rec[1 + n + lane] = 0; // the readers take LIST_GROUP entries at a time
   if (lane == 0)
-    rec[0] = n <= WORDS - 1 ? n : -1;
+    rec[0] = n <= WORDS - LIST_GROUP ? n : -1;
 }
 
 // ---------------------------------------------------------------------------

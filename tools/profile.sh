@@ -29,3 +29,6 @@ pass pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 python3 $ROOT/tools/summarize_prof.py "$OUT" "$WORKLOAD" "$OUT/counters.json" $ONE_LAUNCH > "$OUT/summary.txt" 2>&1
 grep -A40 "== per frame" "$OUT/summary.txt"
 grep '"metric"' "$OUT/stats.log" > "$OUT/bench_line_under_rocprof.json"
+# the passes' databases are tens of megabytes each and summarised above: only the
+# text travels back
+for d in stats pmc_sq pmc_sq2 pmc_lds pmc_fetch pmc_write; do rm -rf "$OUT/$d"; done
