@@ -96,6 +96,7 @@ constexpr int LIST_GROUP = 4;
 constexpr int BIN_CAP = BIN_WORDS - LIST_GROUP;
 constexpr int BIN_SUPER_PX = 128;     // the lists are made in two levels (k_bin_spheres)
 constexpr int BIN_SUPER_WORDS = 1024;
+constexpr int BIN_SUPER_SLICES = 8;   // lists per first-level cell, one per range of spheres
 static_assert(BIN_SUPER_PX % BIN_PX == 0, "a cell has one parent");
 
 struct CameraDev {

@@ -501,38 +501,56 @@ __global__ __launch_bounds__(64) void k_bin_spheres(SceneDev sc, CameraDev cam, 
   const bool lv = lane < 4;
   const float a = dot3(dx, dy, dz, dx, dy, dz);
   const Beam B = make_beam(lv, a, dx, dy, dz, cam.ox, cam.oy, cam.oz, 0.f, 9.5367431640625e-07f);
-  int32_t *const rec = out + ((size_t)blockIdx.y * out_x + blockIdx.x) * WORDS;
-  const int32_t *src = nullptr;
-  int n_src = sc.s_size;
-  if (FROM_LIST) {
-    src = parent + ((size_t)(i0 / BIN_SUPER_PX) * parent_x + j0 / BIN_SUPER_PX) * BIN_SUPER_WORDS;
-    n_src = src[0];
-  }
-  if (!B.narrow || n_src < 0) {
+  // The first level cuts the spheres into BIN_SUPER_SLICES ranges, one wave and one
+  // list per range (blockIdx.z), so that a change of camera is not 157 dependent
+  // rounds of 64 spheres for a few hundred waves; the second level reads a parent's
+  // lists one after the other, which keeps the indices in rising order.
+  int32_t *const rec = out + ((size_t)blockIdx.y * out_x + blockIdx.x) * WORDS +
+                       (FROM_LIST ? 0 : blockIdx.z * (WORDS / BIN_SUPER_SLICES));
+  constexpr int CAP = (FROM_LIST ? WORDS : WORDS / BIN_SUPER_SLICES) - LIST_GROUP;
+  if (!B.narrow) {
     if (lane == 0)
       rec[0] = -1;
     return;
   }
   int n = 0;
-  for (int base = 0; base < n_src; base += 64) {
-    const int k = base + lane;
-    int idx = k < n_src ? k : n_src - 1;
-    if (FROM_LIST)
-      idx = src[1 + idx];
-    const float4 g = sc.sph_geo[idx];
-    const bool keep = k < n_src && beam_keeps(B, g);
-    const unsigned long long m = __ballot(keep);
-    if (keep) {
-      const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      if (pos < WORDS - LIST_GROUP)
-        rec[1 + pos] = idx;
+  const int per_slice = (sc.s_size + BIN_SUPER_SLICES - 1) / BIN_SUPER_SLICES;
+  for (int z = 0; z < (FROM_LIST ? BIN_SUPER_SLICES : 1); z++) {
+    const int32_t *src = nullptr;
+    int first = 0, n_src;
+    if (FROM_LIST) {
+      src = parent + ((size_t)(i0 / BIN_SUPER_PX) * parent_x + j0 / BIN_SUPER_PX) * BIN_SUPER_WORDS +
+            z * (BIN_SUPER_WORDS / BIN_SUPER_SLICES);
+      n_src = src[0];
+      if (n_src < 0) {
+        if (lane == 0)
+          rec[0] = -1;
+        return;
+      }
+    } else {
+      first = blockIdx.z * per_slice;
+      n_src = sc.s_size - first < per_slice ? sc.s_size - first : per_slice;
     }
-    n += __builtin_popcountll(m);
+    for (int base = 0; base < n_src; base += 64) {
+      const int k = base + lane;
+      int idx = first + (k < n_src ? k : n_src - 1);
+      if (FROM_LIST)
+        idx = src[1 + idx];
+      const float4 g = sc.sph_geo[idx];
+      const bool keep = k < n_src && beam_keeps(B, g);
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (pos < CAP)
+          rec[1 + pos] = idx;
+      }
+      n += __builtin_popcountll(m);
+    }
   }
-  if (n <= WORDS - LIST_GROUP && lane < LIST_GROUP && n + lane < ((n + LIST_GROUP - 1) & ~(LIST_GROUP - 1)))
+  if (n <= CAP && lane < LIST_GROUP && n + lane < ((n + LIST_GROUP - 1) & ~(LIST_GROUP - 1)))
     rec[1 + n + lane] = 0; // the readers take LIST_GROUP entries at a time
   if (lane == 0)
-    rec[0] = n <= WORDS - LIST_GROUP ? n : -1;
+    rec[0] = n <= CAP ? n : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -767,8 +785,9 @@ hipError_t launch_bin_spheres(const SceneDev &sc, const CameraDev &cam, int w, i
     return hipErrorInvalidValue;
   const int bx = (w + BIN_PX - 1) / BIN_PX, by = (h + BIN_PX - 1) / BIN_PX;
   const int sx = (w + BIN_SUPER_PX - 1) / BIN_SUPER_PX, sy = (h + BIN_SUPER_PX - 1) / BIN_SUPER_PX;
-  hipLaunchKernelGGL((k_bin_spheres<BIN_SUPER_PX, BIN_SUPER_WORDS, false>), dim3(sx, sy), dim3(64), 0,
-                     st, sc, cam, w, h, super, sx, (const int32_t *)nullptr, 0);
+  hipLaunchKernelGGL((k_bin_spheres<BIN_SUPER_PX, BIN_SUPER_WORDS, false>),
+                     dim3(sx, sy, BIN_SUPER_SLICES), dim3(64), 0, st, sc, cam, w, h, super, sx,
+                     (const int32_t *)nullptr, 0);
   hipLaunchKernelGGL((k_bin_spheres<BIN_PX, BIN_WORDS, true>), dim3(bx, by), dim3(64), 0, st, sc,
                      cam, w, h, bins, bx, (const int32_t *)super, sx);
   return hipGetLastError();
