@@ -304,6 +304,17 @@ int rt_render_device_selfcheck(rt_scene *scene, const camera *cam,
                                const rt_frame *frame, uint64_t *dev_ray_count,
                                uint64_t *dev_stats);
 
+/* Self-check of the sphere lists of the primary pass (rt_scene_set_screen): for
+ * every pixel ray of a w x h frame of this camera, and for every shadow ray of
+ * the pixels' hits towards a light that has lists, every sphere of the scene is
+ * put through the discriminant test of maths.cpp:132-133; a sphere that passes
+ * must be in the list of the ray's cell.  Slow (pixels x spheres); blocking.
+ * out[0] pixel rays whose screen cell has a list, out[1] passing spheres missing
+ * from those lists - must be 0, out[2] shadow rays served by a list, out[3]
+ * passing spheres missing from those - must be 0.  No counterpart in the
+ * reference.                                                                  */
+int rt_verify_sphere_lists(rt_scene *scene, const camera *cam, int w, int h, uint64_t out[4]);
+
 /* Host-only self-check of the hierarchy builders (no GPU needed): builds the
  * sphere and the triangle hierarchy for the scene and counts violated
  * invariants.  out (8 x int64): [0] sphere nodes (-1: no hierarchy), [1] spheres

@@ -1061,6 +1061,31 @@ int rt_render_device(rt_scene *S, const camera *cam, const rt_frame *fr,
   return render_device_impl(S, cam, fr, dev_ray_count, nullptr);
 }
 
+int rt_verify_sphere_lists(rt_scene *S, const camera *cam, int w, int h, uint64_t out[4]) {
+  if (!S || !cam || !out)
+    return fail(RT_ERR_BAD_ARG, "scene, camera or out is NULL");
+  if (w <= 0 || h <= 0)
+    return fail(RT_ERR_BAD_ARG, "frame size %d x %d", w, h);
+  for (int k = 0; k < 4; k++)
+    out[k] = 0;
+  HIP_TRY(hipSetDevice(S->device));
+  rt_frame fr;
+  memset(&fr, 0, sizeof fr);
+  fr.w = w;
+  fr.h = h;
+  int rc = scene_set_eye(S, cam, &fr, nullptr, true); // the view's lists, made if need be
+  if (rc)
+    return rc;
+  DevBuf<unsigned long long> dev;
+  HIP_TRY(dev.alloc(4));
+  HIP_TRY(hipMemsetAsync(dev.p, 0, 4 * sizeof(unsigned long long), nullptr));
+  HIP_TRY(rt::launch_verify_lists(S->dev(), camera_dev(cam, w, h), w, h, dev.p, nullptr));
+  HIP_TRY(hipMemcpy(out, dev.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipEventRecord(S->ev_frame, nullptr));
+  S->frame_recorded = true;
+  return RT_OK;
+}
+
 int rt_render_device_selfcheck(rt_scene *S, const camera *cam, const rt_frame *fr,
                                uint64_t *dev_ray_count, uint64_t *dev_stats) {
   if (!dev_stats)

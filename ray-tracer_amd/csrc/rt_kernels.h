@@ -150,6 +150,10 @@ hipError_t launch_bin_spheres(const SceneDev &sc, const CameraDev &cam, int w, i
 // the first of the two levels.
 hipError_t launch_bin_light(const SceneDev &sc, float Xx, float Xy, float Xz, float reach,
                             int32_t *cells, int32_t *super, hipStream_t st);
+// Diagnostic: every sphere against every pixel ray and primary shadow ray of a w x h
+// frame; out (device, 4 x uint64, zeroed by the caller) as described at k_verify_lists.
+hipError_t launch_verify_lists(const SceneDev &sc, const CameraDev &cam, int w, int h,
+                               unsigned long long *out, hipStream_t st);
 // accel: RT_BEAM_NONE (plain loop), RT_BEAM_APEX (screen spheres per wave
 // before the per-ray tests) or RT_ACCEL_BVH (every lane walks the sphere
 // hierarchy); same results, different amounts of work.  verify_stats: device uint64[2] {spheres dropped although a ray's

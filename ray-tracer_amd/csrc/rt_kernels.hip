@@ -613,6 +613,88 @@ __global__ __launch_bounds__(64) void k_bin_light(SceneDev sc, float Xx, float X
 }
 
 // ---------------------------------------------------------------------------
+// k_verify_lists — do the sphere lists hold every sphere a ray could hit?
+// ---------------------------------------------------------------------------
+// One thread per pixel, every sphere of the scene for every ray (slow: a diagnostic).
+// For the pixel's ray from the eye, and for the shadow rays of its hit towards the
+// lights that have lists: a sphere for which the float discriminant test
+// (maths.cpp:132-133) passes must be in the list of the ray's cell.  The lists are
+// in rising index order, so a pointer into the list walks along with the loop over
+// the spheres.  out[0] rays from the eye whose cell has a list, out[1] (ray, sphere)
+// pairs of those with a passing test and the sphere not listed - must be 0,
+// out[2] shadow rays whose cell has a list and whose origin is within reach,
+// out[3] as out[1] for those.
+__global__ __launch_bounds__(256) void k_verify_lists(SceneDev sc, CameraDev cam, int w, int h,
+                                                      unsigned long long *out) {
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15), i = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= h || j >= w)
+    return;
+  float px = (float)((2 * ((j + 0.5) / (double)(float)w) - 1) * cam.tan_half * (double)cam.aspect);
+  float py = (float)((1 - 2 * ((i + 0.5) / (double)(float)h)) * cam.tan_half);
+  float dx = px - cam.ox, dy = py - cam.oy, dz = cam.plane_z - cam.oz;
+  normalize3(dx, dy, dz);
+  const float a = dot3(dx, dy, dz, dx, dy, dz), a4 = 4.0f * a;
+  unsigned long long served = 0, missing = 0, s_served = 0, s_missing = 0;
+  if (sc.bins != nullptr) {
+    const int32_t *rec = sc.bins + ((size_t)(i / BIN_PX) * sc.bins_x + j / BIN_PX) * BIN_WORDS;
+    const int n = rec[0];
+    if (n >= 0) {
+      served = 1;
+      int p = 0;
+      for (int k = 0; k < sc.s_size; k++) {
+        const float4 s = sc.sph_prim[k];
+        const float b = 2.0f * dot3(dx, dy, dz, s.x, s.y, s.z);
+        const bool pass = !(b * b < a4 * s.w);
+        while (p < n && rec[1 + p] < k)
+          p++;
+        if (pass && !(p < n && rec[1 + p] == k))
+          missing++;
+      }
+    }
+  }
+  // the pixel's hit, by the plain loops, and its shadow rays (renderer.cpp:82-119)
+  const Hit hit = trace<true, false, RT_BEAM_NONE>(sc, true, cam.ox, cam.oy, cam.oz, dx, dy, dz);
+  if (hit.kind != 0 && sc.lcells != nullptr) {
+    const Surface sf = surface_at(sc, hit);
+    for (int l = 0; l < sc.lcell_lights; l++) {
+      const float4 light = sc.lights[l];
+      float fColor[3], lx, ly, lz;
+      (void)phong_light(sf, hit, dx, dy, dz, light, fColor, lx, ly, lz);
+      const float dist = length3(light.x - hit.Px, light.y - hit.Py, light.z - hit.Pz);
+      const float sa = dot3(lx, ly, lz, lx, ly, lz);
+      if (!(sa > 0.f) || !(dist <= sc.lcell_reach[l]))
+        continue;
+      const int cell = light_cell<LCELL_R>(hit.Px - light.x, hit.Py - light.y, hit.Pz - light.z);
+      const int32_t *rec = sc.lcells + ((size_t)l * LCELL_COUNT + cell) * LCELL_WORDS;
+      const int n = rec[0];
+      if (n < 0)
+        continue;
+      s_served++;
+      int p = 0;
+      for (int k = 0; k < sc.s_size; k++) {
+        const float4 g = sc.sph_geo[k];
+        const float Lx = hit.Px - g.x, Ly = hit.Py - g.y, Lz = hit.Pz - g.z; // maths.cpp:126
+        const float b = 2.0f * dot3(lx, ly, lz, Lx, Ly, Lz);                 // :128
+        const float c = dot3(Lx, Ly, Lz, Lx, Ly, Lz) - g.w;                  // :129
+        const bool pass = !(b * b < (4.0f * sa) * c);
+        while (p < n && rec[1 + p] < k)
+          p++;
+        if (pass && !(p < n && rec[1 + p] == k))
+          s_missing++;
+      }
+    }
+  }
+  if (served)
+    atomicAdd(out + 0, served);
+  if (missing)
+    atomicAdd(out + 1, missing);
+  if (s_served)
+    atomicAdd(out + 2, s_served);
+  if (s_missing)
+    atomicAdd(out + 3, s_missing);
+}
+
+// ---------------------------------------------------------------------------
 // k_bounce — one bounce level: one queued ray per lane
 // ---------------------------------------------------------------------------
 // The grid is fixed; waves stride over the queue, whose length is read from
@@ -802,6 +884,15 @@ hipError_t launch_bin_light(const SceneDev &sc, float Xx, float Xy, float Xz, fl
                      super, (const int32_t *)nullptr);
   hipLaunchKernelGGL((k_bin_light<LCELL_R, LCELL_WORDS, true>), dim3(LCELL_R, LCELL_R, 6), dim3(64),
                      0, st, sc, Xx, Xy, Xz, reach, cells, (const int32_t *)super);
+  return hipGetLastError();
+}
+
+hipError_t launch_verify_lists(const SceneDev &sc, const CameraDev &cam, int w, int h,
+                               unsigned long long *out, hipStream_t st) {
+  if (w <= 0 || h <= 0 || !out)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_verify_lists, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st, sc, cam, w,
+                     h, out);
   return hipGetLastError();
 }
 

@@ -170,6 +170,8 @@ def lib() -> C.CDLL:
     L.rt_scene_set_side_stream.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_set_one_launch.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_describe.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.rt_verify_sphere_lists.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int,
+                                         C.POINTER(C.c_uint64)]
     L.rt_scene_time_kernels.argtypes = [C.c_void_p, C.c_int]
     L.rt_scene_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.rt_scene_set_rays_per_pixel.argtypes = [C.c_void_p, C.c_int]
@@ -358,6 +360,14 @@ class DeviceScene:
                 "one_launch": bool(info[3]), "triangle_nodes": info[4],
                 "lights_with_lists": info[5], "screen_cells_with_list": info[6],
                 "light_cells_without_list": info[7]}
+
+    def verify_sphere_lists(self, w: int, h: int, cam: Optional[Camera] = None):
+        """rt_verify_sphere_lists: (pixel rays served by a list, passing spheres missing from
+        those lists, shadow rays served, passing spheres missing from theirs)."""
+        cam = cam or default_camera()
+        out = (C.c_uint64 * 4)()
+        _check(lib().rt_verify_sphere_lists(self.handle, C.byref(cam), w, h, out))
+        return tuple(int(x) for x in out)
 
     def time_kernels(self, on: bool = True):
         """rt_scene_time_kernels: record events around the stages of later frames."""

@@ -142,3 +142,20 @@ def test_bounce_frames_with_lists(oracle):
         fb, ids, n = rtamd.render(sc, 240, 160, max_depth=depth)
         assert_frame_parity(fb, ids, fo, io, f"depth {depth}")
         assert n == no
+
+
+def test_no_list_lacks_a_sphere_a_ray_could_hit():
+    """rt_verify_sphere_lists: every sphere against every pixel ray and primary shadow ray; a
+    sphere that passes the reference's discriminant test must be in the ray's list."""
+    for sc, (w, h), cam in [(rtamd.grid_scene(100, 100), (640, 360), None),
+                            (_wild_scene(106, 700), (320, 200), "moved"),
+                            (_cloud(10, 900, n_lights=3), (400, 250), None),
+                            (_cloud(11, 500, n_lights=1, light_at=(0, 0, -90)), (300, 200), "wide")]:
+        c = rtamd.default_camera(140 if cam == "wide" else 90)
+        if cam == "moved":
+            c.origin[0], c.origin[1], c.origin[2] = 3.0, -2.0, 60.0
+        with rtamd.DeviceScene(sc) as ds:
+            served, missing, s_served, s_missing = ds.verify_sphere_lists(w, h, c)
+        assert missing == 0 and s_missing == 0, (served, missing, s_served, s_missing)
+        if cam is None:        # (large spheres and a 140-degree view leave many cells without a list)
+            assert served > 0.5 * w * h and s_served > 0
